@@ -1,0 +1,196 @@
+// wa_decode.cpp - KV-cell bookkeeping and one decoder pass over a batch of tokens.
+//
+// ref: whisper_kv_cache_* whisper.cpp:1049-1167 (cell metadata: pos + set of sequence ids; beams share
+// cells by id, no data copies), whisper_build_graph_decoder whisper.cpp:2474-2852,
+// whisper_decode_internal whisper.cpp:2864-2994.
+#include "wa_internal.h"
+#include "wa_kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+// -------------------------------------------------------------------------------------------------
+// KV cells ("paged" cache: page = one cell)
+// -------------------------------------------------------------------------------------------------
+bool wa_kv_find_slot(wa_kv_cache & c, const wa_batch & b) {
+    const uint32_t n_ctx = c.size, n_tokens = b.n_tokens;
+    if (n_tokens > n_ctx) { WA_ERROR("%s: n_tokens=%d > n_ctx=%d\n", __func__, n_tokens, n_ctx); return false; }
+    uint32_t n_tested = 0;
+    while (true) {
+        if (c.head + n_tokens > n_ctx) { n_tested += n_ctx - c.head; c.head = 0; continue; }
+        bool found = true;
+        for (uint32_t i = 0; i < n_tokens; ++i) {
+            if (c.cells[c.head + i].pos >= 0) { found = false; c.head += i + 1; n_tested += i + 1; break; }
+        }
+        if (found) break;
+        if (n_tested >= n_ctx) return false;
+    }
+    for (uint32_t i = 0; i < n_tokens; ++i) {
+        c.cells[c.head + i].pos = b.pos[i];
+        c.cells[c.head + i].seq_id.insert(b.seq_id[i]);
+    }
+    return true;
+}
+
+int32_t wa_kv_cell_max(const wa_kv_cache & c) {
+    for (uint32_t i = c.size - 1; i > 0; --i)
+        if (c.cells[i].pos >= 0 && !c.cells[i].seq_id.empty()) return i + 1;
+    return 1;
+}
+
+void wa_kv_clear(wa_kv_cache & c) {
+    for (auto & cell : c.cells) { cell.pos = -1; cell.seq_id.clear(); }
+    c.head = 0;
+    // the reference also zeroes the buffer (whisper.cpp:1118); masked cells contribute exactly 0 to the
+    // softmax and our V rows are always finite, so the data need not be touched here.
+}
+
+void wa_kv_seq_rm(wa_kv_cache & c, int32_t seq, int32_t p0, int32_t p1) {
+    uint32_t new_head = c.size;
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = std::numeric_limits<int32_t>::max();
+    for (uint32_t i = 0; i < c.size; ++i) {
+        auto & cell = c.cells[i];
+        if (cell.pos >= p0 && cell.pos < p1) {
+            if (seq < 0) cell.seq_id.clear();
+            else if (cell.has(seq)) cell.seq_id.erase(seq);
+            else continue;
+            if (cell.seq_id.empty()) { cell.pos = -1; if (new_head == c.size) new_head = i; }
+        }
+    }
+    if (new_head != c.size) c.head = new_head;
+}
+
+void wa_kv_seq_cp(wa_kv_cache & c, int32_t src, int32_t dst, int32_t p0, int32_t p1) {
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = std::numeric_limits<int32_t>::max();
+    c.head = 0;
+    for (auto & cell : c.cells)
+        if (cell.has(src) && cell.pos >= p0 && cell.pos < p1) cell.seq_id.insert(dst);
+}
+
+// -------------------------------------------------------------------------------------------------
+// decoder pass
+// -------------------------------------------------------------------------------------------------
+// small-M products stream the weights once (GEMV, HBM-bound); larger M (prompt) goes to the MFMA GEMM
+static void linear(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
+    if (M <= 8) wa_launch_gemv(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
+    else        wa_launch_gemm(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
+}
+
+bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads, ggml_abort_callback abort_cb,
+               void * abort_data) {
+    const int64_t t0 = wa_time_us();
+    const auto & m  = ctx.model;
+    const auto & hp = m.hp;
+    const int n_vocab = hp.n_vocab, n_tokens = batch.n_tokens;
+    if (n_tokens <= 0 || n_tokens > st.dec_mpad) { WA_ERROR("%s: bad batch size %d\n", __func__, n_tokens); return false; }
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
+
+    auto & kv = st.kv_self;
+    if (!wa_kv_find_slot(kv, batch)) return false;
+    kv.n = std::min(kv.size, (uint32_t) std::max(1, wa_kv_cell_max(kv)));     // padding = 1 (whisper.cpp:2892-2893)
+    const int n_kv = kv.n, kv_head = kv.head;
+
+    st.logits.resize((size_t) n_tokens * n_vocab);
+    if (m.n_loaded == 0) {          // header-only test model
+        std::fill(st.logits.begin(), st.logits.end(), 0.0f);
+        return !(abort_cb && abort_cb(abort_data));
+    }
+
+    const int d = hp.n_text_state, H = hp.n_text_head;
+    const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
+    hipStream_t s = st.stream;
+
+    // ---- inputs: tokens, positions, rows that need logits, KQ mask (whisper.cpp:2912-2956) ----
+    int32_t * h_tok = st.h_stage_i32, * h_pos = h_tok + st.dec_mpad, * h_rows = h_pos + st.dec_mpad;
+    int n_rows = 0;
+    for (int i = 0; i < n_tokens; ++i) {
+        h_tok[i] = batch.token[i];
+        h_pos[i] = batch.pos[i];
+        if (batch.logits[i]) h_rows[n_rows++] = i;
+    }
+    if (n_rows > WA_MAX_DECODERS) { WA_ERROR("%s: too many logits rows requested (%d)\n", __func__, n_rows); return false; }
+    for (int i = 0; i < n_tokens; ++i)
+        if (h_tok[i] < 0 || h_tok[i] >= n_vocab || h_pos[i] < 0 || h_pos[i] >= hp.n_text_ctx) {
+            WA_ERROR("%s: token %d / position %d out of range\n", __func__, h_tok[i], h_pos[i]);
+            return false;
+        }
+    if ((size_t) n_tokens * n_kv > st.h_mask_cap) { WA_ERROR("%s: mask overflow\n", __func__); return false; }
+    int8_t * h_mask = st.h_stage_mask;
+    for (int j = 0; j < n_tokens; ++j) {
+        const int32_t pos = batch.pos[j], seq = batch.seq_id[j];
+        for (int i = 0; i < n_kv; ++i) h_mask[(size_t) j * n_kv + i] = (!kv.cells[i].has(seq) || kv.cells[i].pos > pos) ? 1 : 0;
+    }
+    (void) hipMemcpyAsync(st.d_tok,  h_tok,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    (void) hipMemcpyAsync(st.d_pos,  h_pos,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (n_rows) (void) hipMemcpyAsync(st.d_rows, h_rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
+
+    wa_launch_dec_embed(s, st.d_tok, st.d_pos, n_tokens, d, m.d_te, m.d_pe, st.d_dx);
+
+    const float KQscale = pow(float(64), -0.25);       // whisper.cpp:2522
+    const size_t kv_layer = (size_t) kv.size * d;
+    const size_t cross_layer = (size_t) H * st.cross_tpad * 64;
+
+    for (int il = 0; il < hp.n_text_layer; ++il) {
+        const auto & L = m.dec[il];
+        // ---- masked self-attention ----
+        wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+        {   // fused q|k|v: q scaled -> d_dq ; k scaled, v -> straight into their KV cells [kv_head, kv_head + n_tokens)
+            wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
+            e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
+            e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
+            linear(s, WA_EPI_DEC_QKV, st.d_dxn, d, L.qkv, n_tokens, e);
+        }
+        wa_launch_dec_self_attn(s, st.d_dq, d, kv.k + il * kv_layer, kv.v + il * kv_layer, d, H, n_tokens, n_kv, st.d_mask, st.d_scores,
+                                st.d_dao, d);
+        {
+            wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
+            linear(s, WA_EPI_RESID, st.d_dao, d, L.out, n_tokens, e);
+        }
+        // ---- cross-attention over the encoder K/V ----
+        wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, L.cross_ln.w, L.cross_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+        {
+            wa_epi e; e.bias = L.cross_q.b; e.out = st.d_dq; e.ldo = d;
+            linear(s, WA_EPI_F16, st.d_dxn, d, L.cross_q, n_tokens, e);
+        }
+        float * qk_out = nullptr;
+        if (save_aheads && st.d_aheads_qk && il < (int) st.aheads.size() && !st.aheads[il].empty())
+            qk_out = st.d_aheads_qk + (size_t) il * n_tokens * H * T;
+        wa_launch_dec_cross_attn(s, st.d_dq, d, st.d_cross_k + il * cross_layer, st.d_cross_v + il * cross_layer, st.cross_tpad, T, H,
+                                 n_tokens, KQscale, st.d_scores, st.d_dao, d, qk_out);
+        {
+            wa_epi e; e.bias = L.cross_out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
+            linear(s, WA_EPI_RESID, st.d_dao, d, L.cross_out, n_tokens, e);
+        }
+        // ---- feed-forward ----
+        wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+        {
+            wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_dff; e.ldo = 4 * d;
+            linear(s, WA_EPI_GELU_F16, st.d_dxn, d, L.fc1, n_tokens, e);
+        }
+        {
+            wa_epi e; e.bias = L.fc2.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
+            linear(s, WA_EPI_RESID, st.d_dff, 4 * d, L.fc2, n_tokens, e);
+        }
+    }
+    wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, m.d_ln.w, m.d_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+
+    // logits = token_embedding . x for the flagged rows only (the reference computes all rows and
+    // copies out the flagged ones, whisper.cpp:2835, 2965-2971)
+    if (n_rows) {
+        wa_launch_logits(s, st.d_dxn, d, st.d_rows, n_rows, m.d_te, d, n_vocab, d, st.d_logits);
+        (void) hipMemcpyAsync(st.h_logits_pinned, st.d_logits, (size_t) n_rows * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
+    }
+    if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
+    for (int r = 0; r < n_rows; ++r)
+        memcpy(st.logits.data() + (size_t) h_rows[r] * n_vocab, st.h_logits_pinned + (size_t) r * n_vocab, n_vocab * sizeof(float));
+
+    const int64_t dt = wa_time_us() - t0;
+    if (n_tokens == 1)       { st.t_decode_us += dt; st.n_decode++; }
+    else if (n_tokens < 16)  { st.t_batchd_us += dt; st.n_batchd += n_tokens; }
+    else                     { st.t_prompt_us += dt; st.n_prompt += n_tokens; }
+    return !(abort_cb && abort_cb(abort_data));
+}

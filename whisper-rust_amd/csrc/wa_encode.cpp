@@ -1,0 +1,247 @@
+// wa_encode.cpp - state allocation, log-mel and the encoder pass (conv stem + L x (MHSA, FFN) +
+// cross K/V precompute), as a fixed launch sequence on the state's HIP stream.
+//
+// ref: whisper_init_state whisper.cpp:3390-3561 (allocate once per state), log_mel_spectrogram
+// whisper.cpp:3186-3276, whisper_encode_internal whisper.cpp:2376-2472 and the three graph builders
+// whisper.cpp:1994-2364.  There is no graph IR here: the "graph" is this function.
+#include "wa_internal.h"
+#include "wa_kernels.h"
+
+#include <cmath>
+#include <cstring>
+
+template <typename T> static bool dev_alloc(T *& p, size_t n_elem, bool zero = true) {
+    p = nullptr;
+    const size_t bytes = n_elem * sizeof(T);
+    if (!WA_HIP_OK(hipMalloc((void **) &p, bytes ? bytes : 256))) return false;
+    if (zero && bytes) return WA_HIP_OK(hipMemset(p, 0, bytes));
+    return true;
+}
+template <typename T> static void dev_free(T *& p) { if (p) { (void) hipFree(p); p = nullptr; } }
+
+bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells) {
+    const auto & hp = ctx.model.hp;
+    dev_free(st.kv_self.k);
+    dev_free(st.kv_self.v);
+    st.kv_self.size = n_cells;
+    st.kv_self.head = 0;
+    st.kv_self.n = 0;
+    st.kv_self.cells.assign(n_cells, wa_kv_cell());
+    const size_t n = (size_t) hp.n_text_layer * n_cells * hp.n_text_state;
+    if (!dev_alloc(st.kv_self.k, n) || !dev_alloc(st.kv_self.v, n)) return false;
+    // score scratch must cover max(n_audio_ctx, kv cells) per (token, head)
+    dev_free(st.d_scores);
+    const int ld = std::max(hp.n_audio_ctx, n_cells);
+    if (!dev_alloc(st.d_scores, (size_t) st.dec_mpad * hp.n_text_head * ld, false)) return false;
+    dev_free(st.d_mask);
+    st.d_mask_cap = (size_t) st.dec_mpad * n_cells;
+    if (!dev_alloc(st.d_mask, st.d_mask_cap)) return false;
+    if (st.h_stage_mask) { (void) hipHostFree(st.h_stage_mask); st.h_stage_mask = nullptr; }
+    st.h_mask_cap = st.d_mask_cap;
+    if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_stage_mask, st.h_mask_cap))) return false;
+    return true;
+}
+
+bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
+    const auto & hp = ctx.model.hp;
+    const int d = hp.n_audio_state;
+    st.ctx = &ctx;
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
+    if (!WA_HIP_OK(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking))) return false;
+
+    // ---- encoder ----
+    const int T = hp.n_audio_ctx, tpad = wa_pad(T, WA_TPAD);
+    st.enc_tpad = tpad;
+    st.cross_tpad = tpad;
+    if (!dev_alloc(st.d_mel_max, 1)) return false;
+    // melT: 1 zero row + 2T frames + zero rows so that the strided conv view (3 rows + K padding) stays in bounds
+    if (!dev_alloc(st.d_melT, (size_t) (2 * T + 8) * hp.n_mels + 512)) return false;
+    if (!dev_alloc(st.d_h1,   (size_t) (2 * T + 8) * d)) return false;
+    if (!dev_alloc(st.d_x,    (size_t) tpad * d)) return false;
+    if (!dev_alloc(st.d_xn,   (size_t) tpad * d)) return false;
+    if (!dev_alloc(st.d_qk,   (size_t) tpad * 2 * d)) return false;
+    if (!dev_alloc(st.d_vt,   (size_t) d * tpad)) return false;
+    if (!dev_alloc(st.d_ao,   (size_t) tpad * d)) return false;
+    if (!dev_alloc(st.d_ff,   (size_t) tpad * 4 * d)) return false;
+    if (!dev_alloc(st.d_embd_enc,  (size_t) tpad * d)) return false;
+    if (!dev_alloc(st.d_embd_conv, (size_t) tpad * d)) return false;
+    const size_t n_cross = (size_t) hp.n_text_layer * hp.n_text_head * tpad * 64;
+    if (!dev_alloc(st.d_cross_k, n_cross) || !dev_alloc(st.d_cross_v, n_cross)) return false;
+
+    // ---- decoder ----
+    const int mpad = wa_pad(hp.n_text_ctx, 64);
+    st.dec_mpad = mpad;
+    if (!dev_alloc(st.d_tok, mpad) || !dev_alloc(st.d_pos, mpad) || !dev_alloc(st.d_cell, mpad) || !dev_alloc(st.d_rows, mpad)) return false;
+    if (!dev_alloc(st.d_dx,   (size_t) mpad * d)) return false;
+    if (!dev_alloc(st.d_dxn,  (size_t) mpad * d)) return false;
+    if (!dev_alloc(st.d_dqkv, (size_t) mpad * 3 * d)) return false;
+    if (!dev_alloc(st.d_dao,  (size_t) mpad * d)) return false;
+    if (!dev_alloc(st.d_dff,  (size_t) mpad * 4 * d)) return false;
+    if (!dev_alloc(st.d_dq,   (size_t) mpad * d)) return false;
+    if (!dev_alloc(st.d_logits, (size_t) WA_MAX_DECODERS * hp.n_vocab, false)) return false;
+    if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_stage_i32, (size_t) 4 * mpad * sizeof(int32_t)))) return false;
+    st.h_logits_cap = (size_t) WA_MAX_DECODERS * hp.n_vocab;
+    if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_logits_pinned, st.h_logits_cap * sizeof(float)))) return false;
+
+    // self-attention KV: n_text_ctx padded to 256 cells (whisper.cpp:3403-3406)
+    st.kv_self_n_dec = 1;
+    if (!wa_kv_self_realloc(ctx, st, wa_pad(hp.n_text_ctx, 256))) return false;
+
+    st.decoders[0].rng = std::mt19937(0);   // whisper.cpp:3486
+    WA_INFO("%s: kv self size  = %7.2f MB\n", __func__, 2.0 * hp.n_text_layer * st.kv_self.size * d * 2 / 1e6);
+    WA_INFO("%s: kv cross size = %7.2f MB\n", __func__, 2.0 * n_cross * 2 / 1e6);
+    return true;
+}
+
+void wa_state_release(whisper_state & st) {
+    if (st.ctx) (void) hipSetDevice(st.ctx->device);
+    if (st.stream) (void) hipStreamSynchronize(st.stream);
+    dev_free(st.d_mel); dev_free(st.d_pcm); dev_free(st.d_mel_max);
+    dev_free(st.d_melT); dev_free(st.d_h1); dev_free(st.d_x); dev_free(st.d_xn); dev_free(st.d_qk); dev_free(st.d_vt);
+    dev_free(st.d_ao); dev_free(st.d_ff); dev_free(st.d_embd_enc); dev_free(st.d_embd_conv);
+    dev_free(st.d_cross_k); dev_free(st.d_cross_v);
+    dev_free(st.kv_self.k); dev_free(st.kv_self.v);
+    dev_free(st.d_tok); dev_free(st.d_pos); dev_free(st.d_cell); dev_free(st.d_rows); dev_free(st.d_mask);
+    dev_free(st.d_dx); dev_free(st.d_dxn); dev_free(st.d_dqkv); dev_free(st.d_dao); dev_free(st.d_dff); dev_free(st.d_dq);
+    dev_free(st.d_scores); dev_free(st.d_logits); dev_free(st.d_aheads_qk);
+    if (st.h_stage_i32)     { (void) hipHostFree(st.h_stage_i32);     st.h_stage_i32 = nullptr; }
+    if (st.h_stage_mask)    { (void) hipHostFree(st.h_stage_mask);    st.h_stage_mask = nullptr; }
+    if (st.h_logits_pinned) { (void) hipHostFree(st.h_logits_pinned); st.h_logits_pinned = nullptr; }
+    if (st.stream) { (void) hipStreamDestroy(st.stream); st.stream = nullptr; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// log-mel
+// -------------------------------------------------------------------------------------------------
+static bool mel_reserve(whisper_state & st, size_t n) {
+    if (n <= st.d_mel_cap) return true;
+    dev_free(st.d_mel);
+    st.d_mel_cap = 0;
+    if (!dev_alloc(st.d_mel, n, false)) return false;
+    st.d_mel_cap = n;
+    return true;
+}
+
+bool wa_mel_compute(whisper_context & ctx, whisper_state & st, const float * samples, int n_samples) {
+    const int64_t t0 = wa_time_us();
+    const auto & m = ctx.model;
+    if (n_samples <= 0 || !samples) return false;
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
+
+    // frame counts (whisper.cpp:3205-3225): 30 s of zero padding + 200 reflected samples each side
+    const int64_t padded = (int64_t) n_samples + 480000 + 400;
+    st.mel_n_mel     = m.n_mel_filt;
+    st.mel_n_len     = (int) ((padded - 400) / 160);
+    st.mel_n_len_org = 1 + (n_samples + 200 - 400) / 160;
+    if (!mel_reserve(st, (size_t) st.mel_n_mel * st.mel_n_len)) return false;
+
+    // the samples may already live in HBM (bench / chunk sharding) - then no copy at all
+    const float * d_pcm = nullptr;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, samples) == hipSuccess && attr.type == hipMemoryTypeDevice) {
+        d_pcm = samples;
+    } else {
+        (void) hipGetLastError();   // clear the "invalid value" left by a plain host pointer
+        if ((size_t) n_samples > st.d_pcm_cap) {
+            dev_free(st.d_pcm);
+            st.d_pcm_cap = 0;
+            if (!dev_alloc(st.d_pcm, (size_t) n_samples, false)) return false;
+            st.d_pcm_cap = n_samples;
+        }
+        if (!WA_HIP_OK(hipMemcpyAsync(st.d_pcm, samples, (size_t) n_samples * sizeof(float), hipMemcpyHostToDevice, st.stream))) return false;
+        d_pcm = st.d_pcm;
+    }
+    wa_launch_mel(st.stream, d_pcm, n_samples, m.d_hann, m.d_sincos, m.d_filters, st.mel_n_mel, m.n_fft_filt, st.d_mel, st.mel_n_len,
+                  st.d_mel_max);
+    if (!WA_HIP_OK(hipStreamSynchronize(st.stream))) return false;   // host PCM buffer may be released by the caller
+    st.t_mel_us += wa_time_us() - t0;
+    return true;
+}
+
+bool wa_mel_set(whisper_context & ctx, whisper_state & st, const float * data, int n_len, int n_mel) {
+    if (n_mel != ctx.model.n_mel_filt) {
+        WA_ERROR("%s: invalid number of mel bands: %d (expected %d)\n", __func__, n_mel, ctx.model.n_mel_filt);
+        return false;
+    }
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
+    st.mel_n_len = n_len; st.mel_n_len_org = n_len; st.mel_n_mel = n_mel;
+    if (!mel_reserve(st, (size_t) n_len * n_mel)) return false;
+    if ((size_t) n_len * n_mel)
+        if (!WA_HIP_OK(hipMemcpy(st.d_mel, data, (size_t) n_len * n_mel * sizeof(float), hipMemcpyDefault))) return false;
+    return true;
+}
+
+// -------------------------------------------------------------------------------------------------
+// encoder
+// -------------------------------------------------------------------------------------------------
+bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_abort_callback abort_cb, void * abort_data) {
+    const int64_t t0 = wa_time_us();
+    const auto & m  = ctx.model;
+    const auto & hp = m.hp;
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
+    if (m.n_loaded == 0) {           // header-only test model: nothing to compute (whisper.cpp:1959-1960)
+        st.t_encode_us += wa_time_us() - t0; st.n_encode++;
+        return !(abort_cb && abort_cb(abort_data));
+    }
+    if (!st.d_mel || st.mel_n_mel != hp.n_mels) { WA_ERROR("%s: no mel spectrogram\n", __func__); return false; }
+
+    const int d = hp.n_audio_state, H = hp.n_audio_head;
+    const int T = st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx;     // whisper.cpp:2000
+    const int tpad = st.enc_tpad;
+    hipStream_t s = st.stream;
+    st.enc_n_ctx = T;
+
+    // mel window [offset, offset + 2T) -> time-major F16 (zero rows around it = conv padding)
+    const int rows_total = 2 * T + 8;
+    wa_launch_mel_window(s, st.d_mel, hp.n_mels, st.mel_n_len, mel_offset, 2 * T, st.d_melT, rows_total);
+
+    // conv1 (k3 s1 p1) + bias + GELU: out row t reads melT rows t..t+2 == one contiguous K = 3*n_mels run
+    {
+        wa_epi e; e.bias = m.conv1.b; e.gelu = m.d_gelu; e.out = st.d_h1 + d; e.ldo = d;   // row 0 of h1 stays zero
+        wa_launch_gemm(s, WA_EPI_GELU_F16, st.d_melT, hp.n_mels, m.conv1.w, m.conv1_kpad, 2 * T, d, m.conv1_kpad, e);
+    }
+    // rows of h1 beyond 2T must read as zero for conv2's right padding: they are never written.
+    // conv2 (k3 s2 p1) + bias + GELU, then + positional embedding: out row t reads h1 rows 2t..2t+2 (with the +1 shift)
+    {
+        wa_epi e; e.bias = m.conv2.b; e.gelu = m.d_gelu; e.out = st.d_x; e.ldo = d; e.resid = m.e_pe; e.ldr = d; e.dbg = st.d_embd_conv;
+        wa_launch_gemm(s, WA_EPI_CONV2, st.d_h1, 2 * d, m.conv2.w, 3 * d, T, d, 3 * d, e);
+    }
+
+    const float KQscale = 1.0f / sqrtf(float(64));    // whisper.cpp:2087
+    for (int il = 0; il < hp.n_audio_layer; ++il) {
+        const auto & L = m.enc[il];
+        wa_launch_layernorm(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        {   // fused Q | K | V projection; V lands transposed for the P V product
+            wa_epi e; e.bias = L.qkv.b; e.out = st.d_qk; e.ldo = 2 * d; e.out2 = st.d_vt; e.ldo2 = tpad; e.split0 = 2 * d;
+            wa_launch_gemm(s, WA_EPI_ENC_QKV, st.d_xn, d, L.qkv.w, d, T, 3 * d, d, e);
+        }
+        wa_launch_enc_attn(s, st.d_qk, 2 * d, st.d_vt, tpad, T, d, H, KQscale, st.d_ao, d);
+        {   // out projection + bias + residual
+            wa_epi e; e.bias = L.out.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d;
+            wa_launch_gemm(s, WA_EPI_RESID, st.d_ao, d, L.out.w, d, T, d, d, e);
+        }
+        wa_launch_layernorm(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        {
+            wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_ff; e.ldo = 4 * d;
+            wa_launch_gemm(s, WA_EPI_GELU_F16, st.d_xn, d, L.fc1.w, d, T, 4 * d, d, e);
+        }
+        {
+            wa_epi e; e.bias = L.fc2.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d;
+            wa_launch_gemm(s, WA_EPI_RESID, st.d_ff, 4 * d, L.fc2.w, 4 * d, T, d, 4 * d, e);
+        }
+    }
+    // ln_post -> F32 encoder output (API / tests) + F16 copy (operand of the cross K/V GEMM)
+    wa_launch_layernorm(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, st.d_xn, d, st.d_embd_enc, d);
+
+    // cross-attention K/V of ALL decoder layers in one GEMM (whisper.cpp:2290-2364):
+    // K = (Wk enc) * d_h^-1/4, V = Wv enc + b, both F16, laid out [layer][head][t][64]
+    {
+        wa_epi e; e.bias = m.cross_kv.b; e.scale = m.cross_kv.s; e.out = st.d_cross_k; e.out2 = st.d_cross_v; e.aux0 = st.cross_tpad; e.aux1 = d;
+        wa_launch_gemm(s, WA_EPI_CROSS_KV, st.d_xn, d, m.cross_kv.w, d, T, hp.n_text_layer * 2 * d, d, e);
+    }
+    if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
+    st.have_enc = true;
+    st.t_encode_us += wa_time_us() - t0;
+    st.n_encode++;
+    return !(abort_cb && abort_cb(abort_data));
+}

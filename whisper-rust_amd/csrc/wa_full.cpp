@@ -1,0 +1,562 @@
+// wa_full.cpp - host side of whisper_full_with_state: seek loop over 30 s windows, temperature
+// fallback ladder, prompt construction, logits filtering, greedy / beam sampling, segment assembly.
+//
+// Behavioural contract: sys/whisper.cpp/src/whisper.cpp:6795-7711 (loop), 6109-6417 (logit rules),
+// 6432-6613 (sampling and scoring).  The structure below is our own (one runner object per call,
+// explicit phases); every rule cites the reference lines it reproduces.  All device work goes through
+// wa_encode / wa_decode.
+#include "wa_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <regex>
+
+void wa_dtw_timestamps(whisper_context * ctx, whisper_state * st, const whisper_full_params & params, int i_segment, size_t n_segments,
+                       int seek, int n_frames, int medfilt_width);   // wa_dtw.cpp
+
+namespace {
+
+const char * const k_non_speech[] = {   // whisper.cpp:6102-6107
+    "\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^",
+    "_", "`", "{", "|", "}", "~", "「", "」", "『", "』", "<<", ">>", "<<<", ">>>", "--",
+    "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))", "[[", "]]", "{{", "}}", "♪♪",
+    "♪♪♪", "♩", "♪", "♫", "♬", "♭", "♮", "♯",
+};
+
+// log-softmax / softmax over the filtered logits (whisper.cpp:6109-6143): sequential F32 sums
+void compute_logprobs(const float * logits, int n, float * logprobs) {
+    float mx = logits[0];
+    for (int i = 1; i < n; ++i) if (logits[i] > mx) mx = logits[i];
+    float lse = 0.0f;
+    for (int i = 0; i < n; ++i) if (logits[i] > -INFINITY) lse += expf(logits[i] - mx);
+    lse = logf(lse) + mx;
+    for (int i = 0; i < n; ++i) logprobs[i] = logits[i] > -INFINITY ? logits[i] - lse : -INFINITY;
+}
+void compute_probs(const float * logits, int n, const float * logprobs, float * probs) {
+    for (int i = 0; i < n; ++i) probs[i] = logits[i] == -INFINITY ? 0.0f : expf(logprobs[i]);
+}
+
+struct beam_candidate { int decoder_idx; int seek_delta; bool has_ts; wa_sequence sequence; };
+
+bool same_tokens(const wa_sequence & a, const wa_sequence & b) {   // whisper.cpp:6419-6430
+    if (a.tokens.size() != b.tokens.size()) return false;
+    for (int i = (int) a.tokens.size() - 1; i >= 0; --i) if (a.tokens[i].id != b.tokens[i].id) return false;
+    return true;
+}
+
+struct runner {
+    whisper_context * ctx;
+    whisper_state   * st;
+    whisper_full_params p;
+    const wa_vocab & vocab;
+    const int n_vocab;
+    std::vector<int> suppress_ids;      // tokens killed by suppress_regex / suppress_nst, resolved once per call
+    int blank_id = -1;
+
+    runner(whisper_context * c, whisper_state * s, const whisper_full_params & params)
+        : ctx(c), st(s), p(params), vocab(c->vocab), n_vocab(c->vocab.n_vocab) {}
+
+    void resolve_suppress_lists() {
+        auto sp = vocab.token_to_id.find(" ");
+        blank_id = sp == vocab.token_to_id.end() ? -1 : sp->second;   // the reference throws here (whisper.cpp:6191); we skip
+        if (p.suppress_regex) {                                        // whisper.cpp:6232-6239
+            std::regex re(p.suppress_regex);
+            for (const auto & kv : vocab.token_to_id) if (std::regex_match(kv.first, re)) suppress_ids.push_back(kv.second);
+        }
+        if (p.suppress_nst) {                                          // whisper.cpp:6243-6260
+            for (const char * t : k_non_speech) {
+                const std::string a = t, b = " " + a;
+                for (const auto & s : { a, b }) { auto it = vocab.token_to_id.find(s); if (it != vocab.token_to_id.end()) suppress_ids.push_back(it->second); }
+            }
+            for (const char * t : { " -", " '" }) { auto it = vocab.token_to_id.find(t); if (it != vocab.token_to_id.end()) suppress_ids.push_back(it->second); }
+        }
+    }
+
+    // ---- whisper_process_logits (whisper.cpp:6149-6417) ----
+    void process_logits(wa_decoder & dec, float temperature) {
+        const auto & cur = dec.sequence.tokens;
+        const bool is_initial = cur.empty();
+        const int n = n_vocab;
+        dec.logits.resize(n); dec.probs.resize(n); dec.logprobs.resize(n);
+        float * logits = dec.logits.data();
+        memcpy(logits, st->logits.data() + (size_t) dec.i_batch * n, n * sizeof(float));
+        if (temperature > 0.0f) for (int i = 0; i < n; ++i) logits[i] /= temperature;
+
+        if (p.suppress_blank && is_initial) { logits[vocab.token_eot] = -INFINITY; if (blank_id >= 0) logits[blank_id] = -INFINITY; }
+        logits[vocab.token_not] = -INFINITY;
+        if (p.no_timestamps) for (int i = vocab.token_beg; i < n; ++i) logits[i] = -INFINITY;
+        logits[vocab.token_sot] = -INFINITY;
+        logits[vocab.token_nosp] = -INFINITY;
+        if (!p.tdrz_enable) logits[vocab.token_solm] = -INFINITY;
+        logits[vocab.token_translate] = -INFINITY;
+        logits[vocab.token_transcribe] = -INFINITY;
+        logits[vocab.token_prev] = -INFINITY;
+        for (int i = 0; i < 100; ++i) { const int t = vocab.token_sot + 1 + i; if (t < n) logits[t] = -INFINITY; }   // all g_lang entries
+        if (p.logits_filter_callback) p.logits_filter_callback(ctx, st, cur.data(), (int) cur.size(), logits, p.logits_filter_callback_user_data);
+        for (int id : suppress_ids) logits[id] = -INFINITY;
+
+        {   // timestamps come in pairs, except directly before EOT (whisper.cpp:6264-6281)
+            const bool last_ts = !cur.empty() && cur.back().id >= vocab.token_beg;
+            const bool penult_ts = cur.size() < 2 || cur[cur.size() - 2].id >= vocab.token_beg;
+            if (last_ts) {
+                if (penult_ts) for (int i = vocab.token_beg; i < n; ++i) logits[i] = -INFINITY;
+                else           for (int i = 0; i < vocab.token_eot; ++i) logits[i] = -INFINITY;
+            }
+        }
+        if (is_initial && p.max_initial_ts > 0.0f) {                   // whisper.cpp:6285-6292
+            const float precision = float(WHISPER_CHUNK_SIZE) / ctx->model.hp.n_audio_ctx;
+            const int tid0 = (int) std::round(p.max_initial_ts / precision);
+            for (int i = vocab.token_beg + tid0 + 1; i < n; ++i) logits[i] = -INFINITY;
+        }
+        if (dec.has_ts) {                                              // monotonic timestamps (whisper.cpp:6296-6302)
+            const int tid0 = dec.seek_delta / 2;
+            for (int i = vocab.token_beg; i < vocab.token_beg + tid0 && i < n; ++i) logits[i] = -INFINITY;
+        }
+        float * logprobs = dec.logprobs.data();
+        compute_logprobs(logits, n, logprobs);
+        {   // if the timestamp mass beats every text token, force a timestamp (whisper.cpp:6309-6333)
+            float ts_logprob = -INFINITY;
+            {
+                float mx = logprobs[vocab.token_beg];
+                for (int i = vocab.token_beg + 1; i < n; ++i) if (logprobs[i] > mx) mx = logprobs[i];
+                float lse = 0.0f;
+                for (int i = vocab.token_beg; i < n; ++i) if (logprobs[i] > -INFINITY) lse += expf(logprobs[i] - mx);
+                if (lse > 0.0f) ts_logprob = logf(lse) + mx;
+            }
+            float max_text = logprobs[0];
+            for (int i = 1; i < vocab.token_beg; ++i) if (logprobs[i] > max_text) max_text = logprobs[i];
+            if (ts_logprob > max_text) for (int i = 0; i < vocab.token_beg; ++i) { logits[i] = -INFINITY; logprobs[i] = -INFINITY; }
+        }
+        compute_probs(logits, n, logprobs, dec.probs.data());
+    }
+
+    // timestamp statistics shared by both samplers (whisper.cpp:6447-6465 / 6529-6547)
+    void ts_stats(const wa_decoder & dec, int & tid, float & pt, float & ptsum, int tid_init) const {
+        double sum_ts = 0.0, max_ts = 0.0;
+        tid = tid_init;
+        for (int i = vocab.token_beg; i < n_vocab; ++i) {
+            const float pr = dec.probs[i];
+            if (pr == -INFINITY) continue;
+            sum_ts += pr;
+            if (max_ts < pr) { max_ts = pr; tid = i; }
+        }
+        pt = (float) (max_ts / (sum_ts + 1e-10));
+        ptsum = (float) sum_ts;
+    }
+
+    whisper_token_data sample_token(const wa_decoder & dec, bool best) const {        // whisper.cpp:6432-6489
+        whisper_token_data r = { 0, 0, 0.0f, 0.0f, 0.0f, 0.0f, -1, -1, -1, 0.0f };
+        ts_stats(dec, r.tid, r.pt, r.ptsum, 0);
+        if (best) {
+            for (int i = 0; i < n_vocab; ++i) if (r.p < dec.probs[i]) { r.id = i; r.p = dec.probs[i]; r.plog = dec.logprobs[i]; }
+        } else {
+            std::discrete_distribution<> dist(dec.probs.begin(), dec.probs.end());
+            r.id = dist(dec.rng);
+            r.p = dec.probs[r.id];
+            r.plog = dec.logprobs[r.id];
+        }
+        if (r.id >= vocab.token_beg) { r.tid = r.id; r.pt = r.p; }
+        return r;
+    }
+
+    std::vector<whisper_token_data> sample_token_topk(wa_decoder & dec, int k) const { // whisper.cpp:6491-6564
+        // (the reference also partial-sorts logits_id here; the result is unused, so is the sort)
+        int tid; float pt, ptsum;
+        ts_stats(dec, tid, pt, ptsum, vocab.token_beg);
+        std::discrete_distribution<> dist(dec.probs.begin(), dec.probs.end());
+        std::vector<whisper_token_data> out;
+        out.reserve(k);
+        for (int i = 0; i < k; ++i) {
+            const int id = dist(dec.rng);
+            whisper_token_data t = { id, tid, dec.probs[id], dec.logprobs[id], pt, ptsum, -1, -1, -1, 0.0f };
+            if (t.id >= vocab.token_beg) { t.tid = t.id; t.pt = t.p; }
+            out.push_back(t);
+        }
+        return out;
+    }
+
+    void sequence_score(wa_sequence & seq) const {                                      // whisper.cpp:6567-6613
+        if (seq.result_len == 0) return;
+        double result = 0.0;
+        for (int i = 0; i < seq.result_len; ++i) result += seq.tokens[i].plog;
+        seq.sum_logprobs = result;
+        seq.avg_logprobs = result / seq.result_len;
+        double penalty = seq.result_len;
+        if (p.length_penalty > 0.0f) penalty = pow((5.0 + penalty) / 6.0, p.length_penalty);
+        seq.score = result / penalty;
+        std::map<whisper_token, int> counts;
+        int cnt = 0;
+        for (int i = std::max(0, seq.result_len - 32); i < seq.result_len; ++i) { counts[seq.tokens[i].id]++; cnt++; }
+        double entropy = 0.0;
+        for (const auto & kv : counts) { const double q = kv.second / (double) cnt; entropy -= q * log(q); }
+        seq.entropy = entropy;
+    }
+
+    void prep_batch(const whisper_token * tokens, int n, int n_past, int seq) {         // whisper.cpp:544-556
+        auto & b = st->batch;
+        b.n_tokens = n;
+        b.token.assign(tokens, tokens + n);
+        b.pos.resize(n); b.seq_id.assign(n, seq); b.logits.assign(n, 0);
+        for (int i = 0; i < n; ++i) b.pos[i] = n_past + i;
+        b.logits[n - 1] = 1;
+    }
+
+    int run(const float * samples, int n_samples);
+};
+
+int runner::run(const float * samples, int n_samples) {
+    auto & result_all = st->result_all;
+    result_all.clear();
+
+    if (n_samples > 0) {
+        if (!wa_mel_compute(*ctx, *st, samples, n_samples)) { WA_ERROR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
+    }
+    // language auto-detect (whisper.cpp:6815-6830)
+    if (p.language == nullptr || strlen(p.language) == 0 || strcmp(p.language, "auto") == 0 || p.detect_language) {
+        std::vector<float> probs(whisper_lang_max_id() + 1, 0.0f);
+        const int lang_id = whisper_lang_auto_detect_with_state(ctx, st, 0, p.n_threads, probs.data());
+        if (lang_id < 0) { WA_ERROR("%s: failed to auto-detect language\n", __func__); return -3; }
+        st->lang_id = lang_id;
+        p.language = whisper_lang_str(lang_id);
+        WA_INFO("%s: auto-detected language: %s (p = %f)\n", __func__, p.language, probs[lang_id]);
+        if (p.detect_language) return 0;
+    }
+    if (p.token_timestamps) WA_WARN("%s: token_timestamps (signal-energy heuristic) is not implemented by this backend; use DTW\n", __func__);
+    if (p.n_grammar_rules > 0) WA_WARN("%s: grammar sampling is not implemented by this backend; rules ignored\n", __func__);
+
+    const int seek_start = p.offset_ms / 10;
+    const int seek_end = p.duration_ms == 0 ? st->mel_n_len_org : seek_start + p.duration_ms / 10;
+    const int delta_min = 10;                       // < 100 ms of audio is not processed (whisper.cpp:6847-6852)
+    if (seek_end < seek_start + delta_min) {
+        WA_WARN("%s: input is too short - %d ms < 100 ms. consider padding the input audio with silence\n", __func__, (seek_end - seek_start) * 10);
+        return 0;
+    }
+
+    std::vector<float> temperatures;                // whisper.cpp:6856-6863
+    if (p.temperature_inc > 0.0f) for (float t = p.temperature; t < 1.0f + 1e-6f; t += p.temperature_inc) temperatures.push_back(t);
+    else temperatures.push_back(p.temperature);
+
+    int n_decoders = 1;
+    if (p.strategy == WHISPER_SAMPLING_GREEDY) n_decoders = p.greedy.best_of;
+    else if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) n_decoders = std::max(p.greedy.best_of, p.beam_search.beam_size);
+    n_decoders = std::max(1, n_decoders);
+    if (n_decoders > WA_MAX_DECODERS) { WA_ERROR("%s: too many decoders requested (%d), max = %d\n", __func__, n_decoders, WA_MAX_DECODERS); return -4; }
+    for (int j = 1; j < n_decoders; ++j) st->decoders[j].rng = std::mt19937(j);     // whisper.cpp:6897
+
+    auto & prompt_past = st->prompt_past;
+    if (p.no_context) prompt_past.clear();
+    std::vector<whisper_token> prompt_tokens;
+    if (!p.prompt_tokens && p.initial_prompt) {     // whisper.cpp:6911-6921
+        auto toks = wa_tokenize(vocab, p.initial_prompt);
+        prompt_tokens.assign(toks.begin(), toks.end());
+        p.prompt_tokens = prompt_tokens.data();
+        p.prompt_n_tokens = (int) prompt_tokens.size();
+    }
+    if (p.prompt_tokens && p.prompt_n_tokens > 0) { // prepended to prompt_past (whisper.cpp:6924-6930)
+        for (int i = 0; i < p.prompt_n_tokens; ++i) prompt_past.push_back(p.prompt_tokens[i]);
+        std::rotate(prompt_past.begin(), prompt_past.end() - p.prompt_n_tokens, prompt_past.end());
+    }
+    if (p.audio_ctx > ctx->model.hp.n_audio_ctx) {
+        WA_ERROR("%s: audio_ctx is larger than the maximum allowed (%d > %d)\n", __func__, p.audio_ctx, ctx->model.hp.n_audio_ctx);
+        return -5;
+    }
+    st->exp_n_audio_ctx = p.audio_ctx;
+
+    std::vector<whisper_token> prompt_init = { vocab.token_sot };     // whisper.cpp:6941-6965
+    if (vocab.is_multilingual()) {
+        const int lang_id = whisper_lang_id(p.language);
+        st->lang_id = lang_id;
+        prompt_init.push_back(vocab.token_sot + 1 + lang_id);
+        prompt_init.push_back(p.translate ? vocab.token_translate : vocab.token_transcribe);
+    }
+    {
+        const bool is_distil = ctx->model.hp.n_text_layer == 2 && ctx->model.hp.n_vocab != 51866;
+        if (is_distil && !p.no_timestamps) { WA_WARN("%s: using first release distilled models - forcing no_timestamps\n", __func__); p.no_timestamps = true; }
+    }
+    if (p.no_timestamps) prompt_init.push_back(vocab.token_not);
+
+    resolve_suppress_lists();
+
+    const int n_text_ctx = ctx->model.hp.n_text_ctx;
+    int seek = seek_start;
+    std::vector<whisper_token> prompt;
+    prompt.reserve(n_text_ctx);
+    std::vector<std::vector<beam_candidate>> bc_per_dec(n_decoders);
+    std::vector<beam_candidate> beam_candidates;
+
+    while (true) {
+        if (p.progress_callback) p.progress_callback(ctx, st, (100 * (seek - seek_start)) / (seek_end - seek_start), p.progress_callback_user_data);
+        if (seek + delta_min >= seek_end) break;
+        if (p.encoder_begin_callback && !p.encoder_begin_callback(ctx, st, p.encoder_begin_callback_user_data)) {
+            WA_ERROR("%s: encoder_begin_callback returned false - aborting\n", __func__);
+            break;
+        }
+        if (!wa_encode(*ctx, *st, seek, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to encode\n", __func__); return -6; }
+
+        // a very short tail: drop the text context, it tends to make the decoder hallucinate (whisper.cpp:7012-7016)
+        if (seek > seek_start && seek + 500 >= seek_end) prompt_past.clear();
+
+        int best_decoder_id = 0;
+        for (int it = 0; it < (int) temperatures.size(); ++it) {
+            const float t_cur = temperatures[it];
+            int n_dec = 1;                         // whisper.cpp:7023-7042
+            if (p.strategy == WHISPER_SAMPLING_GREEDY) { if (t_cur > 0.0f) n_dec = p.greedy.best_of; }
+            else if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) n_dec = t_cur > 0.0f ? p.greedy.best_of : p.beam_search.beam_size;
+            n_dec = std::max(1, n_dec);
+
+            for (int j = 0; j < n_dec; ++j) {      // whisper.cpp:7047-7069
+                auto & dec = st->decoders[j];
+                dec.sequence.tokens.clear();
+                dec.sequence.result_len = 0;
+                dec.sequence.sum_logprobs_all = 0.0;
+                dec.sequence.sum_logprobs = -INFINITY;
+                dec.sequence.avg_logprobs = -INFINITY;
+                dec.sequence.entropy = 0.0;
+                dec.sequence.score = -INFINITY;
+                dec.seek_delta = 100 * WHISPER_CHUNK_SIZE;
+                dec.failed = dec.completed = dec.has_ts = false;
+            }
+
+            {   // prompt = [prev + last n_take past tokens] + sot/lang/task (whisper.cpp:7073-7085)
+                prompt.clear();
+                if (!prompt_past.empty() && t_cur < 0.5f && p.n_max_text_ctx > 0) {
+                    const int n_take = std::min(std::min(p.n_max_text_ctx, n_text_ctx / 2), int(prompt_past.size()));
+                    prompt = { vocab.token_prev };
+                    prompt.insert(prompt.begin() + 1, prompt_past.end() - n_take, prompt_past.end());
+                }
+                prompt.insert(prompt.end(), prompt_init.begin(), prompt_init.end());
+
+                if (st->kv_self_n_dec < n_dec) {   // grow the self KV for several decoders (whisper.cpp:7095-7113)
+                    const int factor = n_dec > 1 ? n_dec + 2 : 1;
+                    if (!wa_kv_self_realloc(*ctx, *st, wa_pad(n_text_ctx, 256) * factor)) { WA_ERROR("%s: KV cache reallocation failed\n", __func__); return -7; }
+                    st->kv_self_n_dec = n_dec;
+                }
+                wa_kv_clear(st->kv_self);
+                prep_batch(prompt.data(), (int) prompt.size(), 0, 0);
+                if (!wa_decode(*ctx, *st, st->batch, false, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -8; }
+
+                {   // no-speech probability from the unfiltered first logits (whisper.cpp:7124-7134).
+                    // NB the reference passes state->logits here, whose first n_vocab entries are row 0 of the
+                    // prompt decode - NOT the flagged last row - unless the prompt has one token. We mirror that:
+                    // row 0 holds zeros (never written) when the prompt is longer than one token.
+                    std::vector<float> lp(n_vocab), pr(n_vocab);
+                    compute_logprobs(st->logits.data(), n_vocab, lp.data());
+                    compute_probs(st->logits.data(), n_vocab, lp.data(), pr.data());
+                    st->no_speech_prob = pr[vocab.token_nosp];
+                }
+                const int64_t ts = wa_time_us();
+                st->decoders[0].i_batch = (int) prompt.size() - 1;
+                process_logits(st->decoders[0], t_cur);
+                for (int j = 1; j < n_dec; ++j) {
+                    auto & dec = st->decoders[j];
+                    wa_kv_seq_cp(st->kv_self, 0, j, -1, -1);
+                    dec.probs = st->decoders[0].probs; dec.logits = st->decoders[0].logits; dec.logprobs = st->decoders[0].logprobs;
+                }
+                st->t_sample_us += wa_time_us() - ts;
+            }
+
+            for (int i = 0, n_max = n_text_ctx / 2 - 4; i < n_max; ++i) {
+                const int64_t ts0 = wa_time_us();
+                if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) for (auto & bc : bc_per_dec) bc.clear();
+
+                // ---- sample one token per live decoder (whisper.cpp:7169-7227) ----
+                for (int j = 0; j < n_dec; ++j) {
+                    auto & dec = st->decoders[j];
+                    if (dec.completed || dec.failed) continue;
+                    if (p.strategy == WHISPER_SAMPLING_GREEDY) {
+                        dec.sequence.tokens.push_back(sample_token(dec, t_cur < 1e-6f));
+                        dec.sequence.sum_logprobs_all += dec.sequence.tokens.back().plog;
+                    } else {
+                        for (const auto & tok : sample_token_topk(dec, p.beam_search.beam_size)) {
+                            bc_per_dec[j].push_back({ j, dec.seek_delta, dec.has_ts, dec.sequence });
+                            bc_per_dec[j].back().sequence.tokens.push_back(tok);
+                            bc_per_dec[j].back().sequence.sum_logprobs_all += tok.plog;
+                        }
+                    }
+                }
+                beam_candidates.clear();
+                for (const auto & bc : bc_per_dec) {
+                    beam_candidates.insert(beam_candidates.end(), bc.begin(), bc.end());
+                    if (!bc.empty()) st->n_sample += 1;
+                }
+
+                // ---- beam search: keep the best candidates, re-label KV cells (whisper.cpp:7239-7291) ----
+                if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) {
+                    std::sort(beam_candidates.begin(), beam_candidates.end(), [](const beam_candidate & a, const beam_candidate & b) {
+                        if (a.sequence.sum_logprobs_all != b.sequence.sum_logprobs_all) return a.sequence.sum_logprobs_all > b.sequence.sum_logprobs_all;
+                        return a.decoder_idx < b.decoder_idx;
+                    });
+                    uint32_t cur_c = 0;
+                    for (int j = 0; j < n_dec; ++j) {
+                        auto & dec = st->decoders[j];
+                        if (dec.completed || dec.failed) continue;
+                        if (cur_c >= beam_candidates.size()) cur_c = 0;
+                        auto & cur = beam_candidates[cur_c++];
+                        while (beam_candidates.size() > cur_c && same_tokens(beam_candidates[cur_c].sequence, cur.sequence) && i > 0) ++cur_c;
+                        dec.seek_delta = cur.seek_delta;
+                        dec.has_ts = cur.has_ts;
+                        dec.sequence = cur.sequence;
+                        wa_kv_seq_cp(st->kv_self, cur.decoder_idx, WA_MAX_DECODERS + j, -1, -1);
+                    }
+                    for (int j = 0; j < n_dec; ++j) {
+                        auto & dec = st->decoders[j];
+                        if (dec.completed || dec.failed) continue;
+                        wa_kv_seq_rm(st->kv_self, j, -1, -1);
+                        wa_kv_seq_cp(st->kv_self, WA_MAX_DECODERS + j, j, -1, -1);
+                        wa_kv_seq_rm(st->kv_self, WA_MAX_DECODERS + j, -1, -1);
+                    }
+                }
+
+                // ---- per-decoder state machine (whisper.cpp:7297-7379) ----
+                for (int j = 0; j < n_dec; ++j) {
+                    auto & dec = st->decoders[j];
+                    if (dec.completed || dec.failed) continue;
+                    auto & result_len = dec.sequence.result_len;
+                    const auto & token = dec.sequence.tokens.back();
+                    if (token.id > vocab.token_beg) {           // timestamp token: slide the window
+                        const int seek_delta_new = 2 * (token.id - vocab.token_beg);
+                        if (dec.has_ts && dec.seek_delta > seek_delta_new && result_len < i) { dec.failed = true; continue; }   // no going back in time
+                        dec.seek_delta = seek_delta_new;
+                        result_len = i + 1;
+                        dec.has_ts = true;
+                    }
+                    if (token.id == vocab.token_eot || (p.max_tokens > 0 && i >= p.max_tokens) ||
+                        (dec.has_ts && seek + dec.seek_delta + delta_min >= seek_end)) {
+                        if (result_len == 0 && !p.no_timestamps) {
+                            if (seek + dec.seek_delta + delta_min >= seek_end) result_len = i + 1;
+                            else { dec.failed = true; continue; }
+                        }
+                        if (p.single_segment || p.no_timestamps) { result_len = i + 1; dec.seek_delta = 100 * WHISPER_CHUNK_SIZE; }
+                        dec.completed = true;
+                        continue;
+                    }
+                    if (ctx->model.n_loaded == 0) { dec.seek_delta = 100 * WHISPER_CHUNK_SIZE; dec.completed = true; continue; }   // test models
+                    // repetition loop guard (whisper.cpp:7374-7378)
+                    if (i == n_max - 1 && (result_len == 0 || dec.seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) { dec.failed = true; continue; }
+                }
+                {
+                    bool all_done = true;
+                    for (int j = 0; j < n_dec; ++j) if (!st->decoders[j].completed && !st->decoders[j].failed) all_done = false;
+                    if (all_done) break;
+                }
+                st->t_sample_us += wa_time_us() - ts0;
+
+                // ---- next-token logits for every live decoder in ONE decoder pass (whisper.cpp:7403-7434) ----
+                {
+                    auto & b = st->batch;
+                    b.n_tokens = 0; b.token.clear(); b.pos.clear(); b.seq_id.clear(); b.logits.clear();
+                    const int n_past = (int) prompt.size() + i;
+                    for (int j = 0; j < n_dec; ++j) {
+                        auto & dec = st->decoders[j];
+                        if (dec.failed || dec.completed) continue;
+                        dec.i_batch = b.n_tokens;
+                        b.token.push_back(dec.sequence.tokens.back().id);
+                        b.pos.push_back(n_past);
+                        b.seq_id.push_back(j);
+                        b.logits.push_back(1);
+                        b.n_tokens++;
+                    }
+                    if (!wa_decode(*ctx, *st, b, false, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -9; }
+                    const int64_t ts1 = wa_time_us();
+                    for (int j = 0; j < n_dec; ++j) {
+                        auto & dec = st->decoders[j];
+                        if (dec.failed || dec.completed) continue;
+                        process_logits(dec, t_cur);
+                    }
+                    st->t_sample_us += wa_time_us() - ts1;
+                }
+            }
+
+            {   // rank the sequences (whisper.cpp:7484-7517)
+                double best_score = -INFINITY;
+                for (int j = 0; j < n_dec; ++j) {
+                    auto & dec = st->decoders[j];
+                    if (dec.failed) continue;
+                    dec.sequence.tokens.resize(dec.sequence.result_len);
+                    sequence_score(dec.sequence);
+                    if (dec.sequence.result_len > 32 && dec.sequence.entropy < p.entropy_thold) { dec.failed = true; st->n_fail_h++; continue; }
+                    if (best_score < dec.sequence.score) { best_score = dec.sequence.score; best_decoder_id = j; }
+                }
+            }
+            bool success = true;                    // temperature fallback (whisper.cpp:7519-7544)
+            if (it != (int) temperatures.size() - 1) {
+                const auto & dec = st->decoders[best_decoder_id];
+                if (dec.failed || (dec.sequence.avg_logprobs < p.logprob_thold && st->no_speech_prob < p.no_speech_thold)) { success = false; st->n_fail_p++; }
+            }
+            if (success) break;
+        }
+
+        // ---- turn the winning token sequence into segments (whisper.cpp:7547-7707) ----
+        {
+            const auto & best = st->decoders[best_decoder_id];
+            int seek_delta = best.seek_delta;
+            const int result_len = best.sequence.result_len;
+            const auto & tokens_cur = best.sequence.tokens;
+            const size_t n_segments_before = result_all.size();
+            const bool is_no_speech = st->no_speech_prob > p.no_speech_thold && best.sequence.avg_logprobs < p.logprob_thold;
+
+            prompt_past.clear();
+            if (prompt.front() == vocab.token_prev) prompt_past.insert(prompt_past.end(), prompt.begin() + 1, prompt.end() - prompt_init.size());
+            for (int i = 0; i < result_len && !is_no_speech; ++i) prompt_past.push_back(tokens_cur[i].id);
+
+            auto push_segment = [&](int64_t t0, int64_t t1, const std::string & text, int i0, int i1, bool speaker_turn_next) {
+                if (p.print_realtime) {
+                    if (p.print_timestamps) printf("[%lld --> %lld]  %s\n", (long long) t0, (long long) t1, text.c_str());
+                    else { printf("%s", text.c_str()); fflush(stdout); }
+                }
+                wa_segment seg;
+                seg.t0 = t0; seg.t1 = t1; seg.text = text; seg.no_speech_prob = st->no_speech_prob; seg.speaker_turn_next = speaker_turn_next;
+                for (int j = i0; j < i1; ++j) seg.tokens.push_back(tokens_cur[j]);
+                result_all.push_back(std::move(seg));
+                if (p.new_segment_callback && !ctx->params.dtw_token_timestamps) p.new_segment_callback(ctx, st, 1, p.new_segment_callback_user_data);
+            };
+
+            if (!tokens_cur.empty() && ctx->model.n_loaded > 0 && !is_no_speech) {
+                int i0 = 0;
+                int64_t t0 = seek + 2 * (tokens_cur.front().tid - vocab.token_beg);
+                std::string text;
+                bool speaker_turn_next = false;
+                for (int i = 0; i < (int) tokens_cur.size(); ++i) {
+                    if (p.print_special || tokens_cur[i].id < vocab.token_eot) text += whisper_token_to_str(ctx, tokens_cur[i].id);
+                    if (p.tdrz_enable && tokens_cur[i].id == vocab.token_solm) speaker_turn_next = true;
+                    if (tokens_cur[i].id > vocab.token_beg && !p.single_segment) {
+                        const int64_t t1 = seek + 2 * (tokens_cur[i].tid - vocab.token_beg);
+                        if (!text.empty()) push_segment(t0, t1, text, i0, i + 1, speaker_turn_next);
+                        text = "";
+                        while (i < (int) tokens_cur.size() && tokens_cur[i].id > vocab.token_beg) i++;
+                        i--;
+                        t0 = t1;
+                        i0 = i + 1;
+                        speaker_turn_next = false;
+                    }
+                }
+                if (!text.empty()) push_segment(t0, seek + seek_delta, text, i0, (int) tokens_cur.size(), speaker_turn_next);
+            }
+
+            {   // DTW token timestamps (whisper.cpp:7680-7692)
+                const int n_segments = (int) (result_all.size() - n_segments_before);
+                if (ctx->params.dtw_token_timestamps && n_segments) {
+                    const int n_frames = std::min(std::min(WHISPER_CHUNK_SIZE * 100, seek_delta), seek_end - seek);
+                    wa_dtw_timestamps(ctx, st, p, (int) result_all.size() - n_segments, n_segments, seek, n_frames, 7);
+                    if (p.new_segment_callback)
+                        for (int seg = (int) result_all.size() - n_segments; seg < n_segments; seg++)
+                            p.new_segment_callback(ctx, st, seg, p.new_segment_callback_user_data);
+                }
+            }
+            // a lone closing timestamp means "nothing more in this window" (whisper.cpp:7695-7701)
+            const bool single_timestamp_ending = tokens_cur.size() > 1 && tokens_cur[tokens_cur.size() - 2].id < vocab.token_beg &&
+                                                 tokens_cur[tokens_cur.size() - 1].id > vocab.token_beg;
+            if (single_timestamp_ending) seek_delta = std::min(seek_end - seek, WHISPER_CHUNK_SIZE * 100);
+            seek += seek_delta;
+        }
+    }
+    return 0;
+}
+
+} // namespace
+
+int wa_full(whisper_context * ctx, whisper_state * st, whisper_full_params params, const float * samples, int n_samples) {
+    runner r(ctx, st, params);
+    return r.run(samples, n_samples);
+}

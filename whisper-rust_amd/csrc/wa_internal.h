@@ -1,0 +1,254 @@
+// wa_internal.h - internal types of the MI355X Whisper backend (not part of the C ABI).
+//
+// Architecture: a static per-model execution plan, no graph interpreter.
+//   whisper_context : parsed legacy-ggml model; every weight resident in ONE HBM arena in
+//                     kernel-friendly layouts (fused QKV, fused cross-KV, K-padded conv1).
+//   whisper_state   : one HIP stream + a fixed activation arena + KV caches + decode bookkeeping.
+//   kernels         : wa_kernels.hip (hand-written gfx950 HIP), launched in a fixed order by
+//                     wa_encode.cpp / wa_decode.cpp.
+#pragma once
+
+#include "../../include/whisper_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <random>
+#include <set>
+#include <string>
+#include <vector>
+
+#define WA_MAX_DECODERS 8          // ref: whisper.cpp:148 (WHISPER_MAX_DECODERS)
+#define WA_TPAD         128        // activation row padding (GEMM M tile)
+
+// ---------------------------------------------------------------------------------------------
+// logging (ref: whisper.cpp:111-138, 8935-8969: global callback, default prints to stderr)
+// ---------------------------------------------------------------------------------------------
+void wa_log(ggml_log_level level, const char * fmt, ...) __attribute__((format(printf, 2, 3)));
+#define WA_INFO(...)  wa_log(GGML_LOG_LEVEL_INFO,  __VA_ARGS__)
+#define WA_WARN(...)  wa_log(GGML_LOG_LEVEL_WARN,  __VA_ARGS__)
+#define WA_ERROR(...) wa_log(GGML_LOG_LEVEL_ERROR, __VA_ARGS__)
+#define WA_DEBUG(...) do { } while (0)
+
+int64_t wa_time_us();
+
+#define WA_HIP_OK(expr) wa_hip_ok((expr), #expr, __FILE__, __LINE__)
+bool wa_hip_ok(hipError_t e, const char * what, const char * file, int line);
+
+static inline int wa_pad(int x, int n) { return ((x + n - 1) / n) * n; }
+
+// ---------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------
+struct wa_hparams {       // ref: whisper.cpp:623-636
+    int32_t n_vocab = 51864, n_audio_ctx = 1500, n_audio_state = 384, n_audio_head = 6, n_audio_layer = 4;
+    int32_t n_text_ctx = 448, n_text_state = 384, n_text_head = 6, n_text_layer = 4, n_mels = 80, ftype = 1;
+    float   eps = 1e-5f;
+};
+
+struct wa_vocab {         // ref: whisper.cpp:462-491
+    int n_vocab = 51864;
+    std::map<std::string, int> token_to_id;
+    std::vector<std::string>   id_to_token;   // dense, size n_vocab after load
+    int token_eot = 50256, token_sot = 50257, token_translate = 50357, token_transcribe = 50358;
+    int token_solm = 50359, token_prev = 50360, token_nosp = 50361, token_not = 50362, token_beg = 50363;
+    bool is_multilingual() const { return n_vocab >= 51865; }
+    int  num_languages()  const { return n_vocab - 51765 - (is_multilingual() ? 1 : 0); }
+};
+
+typedef uint16_t wa_f16;  // raw IEEE half bits on the host side
+
+struct wa_ln  { const float * w = nullptr; const float * b = nullptr; };
+struct wa_lin { const wa_f16 * w = nullptr; const float * b = nullptr; const float * s = nullptr; int n_out = 0, n_in = 0; };
+
+struct wa_enc_layer {
+    wa_ln  attn_ln, mlp_ln;
+    wa_lin qkv;      // fused [3d][d]: rows 0..d-1 query, d..2d-1 key (bias 0), 2d..3d-1 value
+    wa_lin out, fc1, fc2;
+};
+
+struct wa_dec_layer {
+    wa_ln  attn_ln, cross_ln, mlp_ln;
+    wa_lin qkv;      // fused [3d][d] with per-column scale s[]: q,k columns d_h^-1/4, v columns 1
+    wa_lin out;
+    wa_lin cross_q, cross_out;
+    wa_lin fc1, fc2;
+};
+
+struct wa_model {
+    int type = 0;    // e_model: 1 tiny, 2 base, 3 small, 4 medium, 5 large (ref: whisper.cpp:96-103)
+    wa_hparams hp;
+    int n_mel_filt = 0, n_fft_filt = 0;
+    std::vector<float> filters;     // host copy [n_mel][n_fft]
+    int n_loaded = 0;               // 0 => header/vocab-only test model (ref: whisper.cpp:1959-1960)
+
+    // ---- device (all inside `arena`) ----
+    void * arena = nullptr; size_t arena_size = 0;
+    const float  * d_filters = nullptr;   // [n_mel][n_fft]
+    const float  * d_hann    = nullptr;   // [400]
+    const float  * d_sincos  = nullptr;   // [2][400]  sin then cos (whisper.cpp:3031-3037)
+    const wa_f16 * d_gelu    = nullptr;   // [65536]   F16 GELU table (vec.h:571-585)
+    const float  * e_pe = nullptr;        // [n_audio_ctx][d]
+    wa_lin conv1;                         // w [d][3*n_mels -> padded to mult of 32], k-major (k*n_mels+ic)
+    wa_lin conv2;                         // w [d][3*d], k-major (k*d+ic)
+    int    conv1_kpad = 0;
+    wa_ln  e_ln;
+    std::vector<wa_enc_layer> enc;
+    const float  * d_pe = nullptr;        // [n_text_ctx][d]
+    const wa_f16 * d_te = nullptr;        // [n_vocab][d]
+    wa_ln  d_ln;
+    std::vector<wa_dec_layer> dec;
+    wa_lin cross_kv;                      // fused over ALL decoder layers: [L*2d][d]; per column bias+scale
+};
+
+struct whisper_context {
+    int64_t t_load_us = 0, t_start_us = 0;
+    whisper_context_params params;
+    int device = 0;
+    wa_model model;
+    wa_vocab vocab;
+    whisper_state * state = nullptr;      // default state (only for the non-_no_state constructors)
+    std::string path_model;
+};
+
+// ---------------------------------------------------------------------------------------------
+// KV cell bookkeeping (ref: whisper.cpp:725-750, 1049-1167). Metadata only; data lives in HBM.
+// ---------------------------------------------------------------------------------------------
+struct wa_kv_cell { int32_t pos = -1; std::set<int32_t> seq_id; bool has(int32_t s) const { return seq_id.count(s) != 0; } };
+
+struct wa_kv_cache {
+    uint32_t head = 0, size = 0, n = 0;
+    std::vector<wa_kv_cell> cells;
+    wa_f16 * k = nullptr;     // self: [n_layer][size][d]
+    wa_f16 * v = nullptr;     // self: [n_layer][size][d]
+};
+
+struct wa_batch {             // ref: whisper.cpp:505-513 (one seq id per token is all whisper uses)
+    int n_tokens = 0;
+    std::vector<int32_t> token, pos, seq_id;
+    std::vector<int8_t>  logits;
+};
+
+bool    wa_kv_find_slot(wa_kv_cache & c, const wa_batch & b);
+int32_t wa_kv_cell_max (const wa_kv_cache & c);
+void    wa_kv_clear    (wa_kv_cache & c);
+void    wa_kv_seq_rm   (wa_kv_cache & c, int32_t seq, int32_t p0, int32_t p1);
+void    wa_kv_seq_cp   (wa_kv_cache & c, int32_t src, int32_t dst, int32_t p0, int32_t p1);
+
+// ---------------------------------------------------------------------------------------------
+// decode bookkeeping (ref: whisper.cpp:493-503, 816-853)
+// ---------------------------------------------------------------------------------------------
+struct wa_segment {
+    int64_t t0 = 0, t1 = 0;
+    std::string text;
+    float no_speech_prob = 0.0f;
+    std::vector<whisper_token_data> tokens;
+    bool speaker_turn_next = false;
+};
+
+struct wa_sequence {
+    std::vector<whisper_token_data> tokens;
+    int result_len = 0;
+    double sum_logprobs_all = 0, sum_logprobs = 0, avg_logprobs = 0, entropy = 0, score = 0;
+};
+
+struct wa_decoder {
+    wa_sequence sequence;
+    int  i_batch = 0, seek_delta = 0;
+    bool failed = false, completed = false, has_ts = false;
+    std::vector<float> probs, logits, logprobs;
+    std::vector<std::pair<double, int>> logits_id;
+    mutable std::mt19937 rng;
+};
+
+struct whisper_state {
+    whisper_context * ctx = nullptr;
+    hipStream_t stream = nullptr;
+
+    // timers (ref: whisper.cpp:868-881)
+    int64_t t_sample_us = 0, t_encode_us = 0, t_decode_us = 0, t_batchd_us = 0, t_prompt_us = 0, t_mel_us = 0;
+    int32_t n_sample = 0, n_encode = 0, n_decode = 0, n_batchd = 0, n_prompt = 0, n_fail_p = 0, n_fail_h = 0;
+
+    // ---- log-mel ----
+    int mel_n_len = 0, mel_n_len_org = 0, mel_n_mel = 0;
+    float * d_mel = nullptr; size_t d_mel_cap = 0;      // [n_mel][n_len] f32 (device is the source of truth)
+    float * d_pcm = nullptr; size_t d_pcm_cap = 0;      // staging for host PCM
+    unsigned int * d_mel_max = nullptr;                 // ordered-uint encoding of the running max
+
+    // ---- encoder activations (rows padded to WA_TPAD) ----
+    int enc_n_ctx = 0;            // n_audio_ctx actually encoded (audio_ctx override)
+    int enc_tpad  = 0;
+    wa_f16 * d_melT   = nullptr;  // [2*n_ctx + 2 + pad][n_mels] f16 time-major window (+1 zero row in front)
+    wa_f16 * d_h1     = nullptr;  // [1 + 2*n_ctx + pad][d] f16 conv1 output (+1 zero row in front)
+    float  * d_x      = nullptr;  // [tpad][d] f32 residual stream
+    wa_f16 * d_xn     = nullptr;  // [tpad][d] f16 LN output / attention output (GEMM A operand)
+    wa_f16 * d_qk     = nullptr;  // [tpad][2d] f16 Q | K
+    wa_f16 * d_vt     = nullptr;  // [d][tpad] f16 V transposed
+    wa_f16 * d_ao     = nullptr;  // [tpad][d] f16 attention output
+    wa_f16 * d_ff     = nullptr;  // [tpad][4d] f16 GELU(fc1)
+    float  * d_embd_enc  = nullptr; // [tpad][d] f32 encoder output
+    float  * d_embd_conv = nullptr; // [tpad][d] f32 conv output before pos-emb (tests; may be null)
+    bool     have_enc = false;
+
+    // ---- cross KV (written by the encoder): [n_layer][n_head][ctx_pad][d_h] f16 each ----
+    wa_f16 * d_cross_k = nullptr, * d_cross_v = nullptr;
+    int cross_tpad = 0;
+
+    // ---- self KV ----
+    wa_kv_cache kv_self;
+    int kv_self_n_dec = 0;
+
+    // ---- decoder activations (rows = tokens in the batch, padded) ----
+    int dec_mpad = 0;             // capacity in rows
+    int32_t * d_tok = nullptr, * d_pos = nullptr, * d_cell = nullptr; // [mpad]
+    int8_t  * d_mask = nullptr; size_t d_mask_cap = 0;                // [n_tokens][n_kv] 1 = masked
+    float  * d_dx  = nullptr;     // [mpad][d] f32 residual
+    wa_f16 * d_dxn = nullptr;     // [mpad][d] f16
+    wa_f16 * d_dqkv = nullptr;    // [mpad][3d] f16 (q scaled | k scaled | v)
+    wa_f16 * d_dao = nullptr;     // [mpad][d] f16
+    wa_f16 * d_dff = nullptr;     // [mpad][4d] f16
+    wa_f16 * d_dq  = nullptr;     // [mpad][d] f16 cross query
+    float  * d_scores = nullptr;  // [mpad][n_head][max(n_audio_ctx, kv size)] f32 scratch
+    float  * d_logits = nullptr;  // [mpad][n_vocab] f32
+    int32_t * d_rows = nullptr;   // [mpad] row indices that need logits
+    float  * d_aheads_qk = nullptr; // DTW capture
+
+    // pinned host staging
+    int32_t * h_stage_i32 = nullptr; int8_t * h_stage_mask = nullptr; size_t h_mask_cap = 0;
+    float * h_logits_pinned = nullptr; size_t h_logits_cap = 0;
+
+    wa_batch batch;
+    wa_decoder decoders[WA_MAX_DECODERS];
+
+    std::vector<float> logits;            // [n_tokens][n_vocab] host copy (only flagged rows valid)
+    std::vector<wa_segment> result_all;
+    std::vector<whisper_token> prompt_past;
+    int   lang_id = 0;
+    float no_speech_prob = 0.0f;
+    int32_t exp_n_audio_ctx = 0;
+
+    // DTW (ref: whisper.cpp:856-860, 946-948)
+    std::vector<std::vector<int>> aheads;  // per text layer: list of heads
+    std::vector<float> aheads_cross_QKs_data;
+    int aheads_n = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// internal entry points
+// ---------------------------------------------------------------------------------------------
+bool wa_model_load(whisper_model_loader * loader, whisper_context & ctx);           // wa_loader.cpp
+void wa_model_free(whisper_context & ctx);
+
+bool wa_mel_compute(whisper_context & ctx, whisper_state & st, const float * samples, int n_samples); // wa_encode.cpp
+bool wa_mel_set    (whisper_context & ctx, whisper_state & st, const float * data, int n_len, int n_mel);
+bool wa_encode     (whisper_context & ctx, whisper_state & st, int mel_offset, ggml_abort_callback cb, void * cb_data);
+bool wa_decode     (whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads,
+                    ggml_abort_callback cb, void * cb_data);                         // wa_decode.cpp
+bool wa_state_alloc(whisper_context & ctx, whisper_state & st);
+void wa_state_release(whisper_state & st);
+bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells);
+
+std::vector<int> wa_tokenize(const wa_vocab & vocab, const std::string & text);       // wa_api.cpp
+int  wa_full(whisper_context * ctx, whisper_state * st, whisper_full_params params, const float * samples, int n_samples); // wa_full.cpp

@@ -1,0 +1,81 @@
+// wa_kernels.h - launchers of the hand-written gfx950 kernels (wa_kernels.hip).
+// Every launcher enqueues on `stream` and returns immediately; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+typedef uint16_t wa_f16;
+
+// ---- GEMM epilogue descriptor -----------------------------------------------------------------
+enum wa_epi_mode {
+    WA_EPI_F16 = 0,     // out f16[m][n]            = f16((acc + bias[n]) * scale[n])
+    WA_EPI_ENC_QKV,     // n <  split0: out f16[m][n]          (Q | K, ld = ldo)
+                        // n >= split0: out2 f16[n-split0][m]  (V transposed, ld = ldo2)
+    WA_EPI_GELU_F16,    // out f16[m][n]            = gelu_f16_table(acc + bias[n])
+    WA_EPI_RESID,       // out f32[m][n]            = (acc + bias[n]) + resid[m][n]
+    WA_EPI_CONV2,       // out f32[m][n]            = resid[m][n] + gelu(acc + bias[n]);  dbg[m][n] = gelu(...)
+    WA_EPI_F32,         // out f32[m][n]            = acc (+ bias[n])
+    WA_EPI_CROSS_KV,    // n -> (layer, k|v, head, c): out/out2 f16 [layer][head][aux0 = tpad][64]
+    WA_EPI_DEC_QKV,     // n <  split0: out  f16[m][n]                        (scaled query)
+                        // n <  split1: out2 f16[(row_off + m)][n - split0]   (scaled key  -> KV cell)
+                        // else       : out3 f16[(row_off + m)][n - split1]   (value       -> KV cell)
+};
+
+struct wa_epi {
+    const float * bias  = nullptr;
+    const float * scale = nullptr;
+    void * out  = nullptr; int ldo  = 0;
+    void * out2 = nullptr; int ldo2 = 0;
+    void * out3 = nullptr; int ldo3 = 0;
+    const float * resid = nullptr; int ldr = 0;
+    float * dbg = nullptr;
+    const wa_f16 * gelu = nullptr;
+    int split0 = 0, split1 = 0;
+    int row_off = 0;
+    int aux0 = 0, aux1 = 0;
+};
+
+// C[M x N] = A[M x K] (f16, row stride lda) * W[N x K]^T (f16, row stride ldw); K % 32 == 0.
+// MFMA path (any M); rows/cols beyond M/N are neither read out of bounds (clamped) nor stored.
+void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw,
+                    int M, int N, int K, const wa_epi & e);
+
+// Same contract, M <= 8: weight-streaming GEMV (LDS dot product, no MFMA) for the decode step.
+void wa_launch_gemv(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw,
+                    int M, int N, int K, const wa_epi & e);
+
+// Row gather for the logits GEMV: A_rows[i] = A[rows[i]] handled inside via `rows` (may be null).
+void wa_launch_logits(hipStream_t stream, const wa_f16 * A, int lda, const int32_t * rows, int n_rows,
+                      const wa_f16 * W, int ldw, int N, int K, float * out /*[n_rows][N]*/);
+
+// ---- log-mel ------------------------------------------------------------------------------------
+// pcm: device f32[n_samples]. mel: device f32[n_mel][n_len]. mel_max: device scratch (1 uint).
+void wa_launch_mel(hipStream_t stream, const float * pcm, int n_samples, const float * hann, const float * sincos,
+                   const float * filters, int n_mel, int n_fft_bins, float * mel, int n_len, unsigned int * mel_max);
+
+// mel window [seek, seek + 2*n_ctx) -> time-major f16 with one zero row in front and zero rows behind
+void wa_launch_mel_window(hipStream_t stream, const float * mel, int n_mel, int n_len, int seek, int n_frames,
+                          wa_f16 * melT, int rows_total);
+
+// ---- LayerNorm: y = ((x - mean) * rsqrt(var + eps)) * w + b;  out16 f16 and/or out32 f32 -----------
+void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b,
+                         float eps, wa_f16 * out16, int ld16, float * out32, int ld32);
+
+// ---- encoder self-attention (exact softmax, two sweeps): qk [T][2d] (Q | K), vt [d][tpad] ----------
+void wa_launch_enc_attn(hipStream_t stream, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d,
+                        int n_head, float scale, wa_f16 * out, int ldo);
+
+// ---- decoder ------------------------------------------------------------------------------------
+void wa_launch_dec_embed(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d,
+                         const wa_f16 * te, const float * pe, float * x);
+
+// masked self-attention over KV cells; mask int8 [n_tokens][n_kv] (1 = masked out)
+void wa_launch_dec_self_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kcache, const wa_f16 * vcache,
+                             int d, int n_head, int n_tokens, int n_kv, const int8_t * mask, float * scores_scratch,
+                             wa_f16 * out, int ldo);
+
+// cross-attention over the encoder K/V: kc/vc [n_head][tpad][64] for this layer.
+// qk_out (optional, DTW): f32 [n_tokens][n_head][T] softmax probabilities.
+void wa_launch_dec_cross_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kc, const wa_f16 * vc,
+                              int tpad, int T, int n_head, int n_tokens, float scale, float * scores_scratch,
+                              wa_f16 * out, int ldo, float * qk_out);

@@ -1,0 +1,759 @@
+// wa_kernels.hip - hand-written gfx950 (CDNA4, wave64) kernels of the Whisper hot path.
+//
+// Numerics contract (DESIGN.md "Rounding points"): the parity target is the reference's ggml-cpu
+// pipeline, which rounds every GEMM activation operand to F16, accumulates in F32, keeps K/V and the
+// softmax probabilities in F16 and evaluates GELU through a 64K-entry F16 table
+// (ggml-cpu.c:1331-1366, ggml.c:3929, whisper.cpp:2181-2202, vec.h:571-585).  Every kernel below
+// rounds at exactly those points; only the F32 summation ORDER differs (MFMA / wave reductions).
+// The file is compiled with -ffp-contract=off: an fma appears only where it is written.
+#include "wa_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 h16;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+__device__ __forceinline__ float h2f(wa_f16 v) { union { wa_f16 u; h16 h; } c; c.u = v; return (float) c.h; }
+__device__ __forceinline__ wa_f16 f2h(float v) { union { wa_f16 u; h16 h; } c; c.h = (h16) v; return c.u; }   // RNE
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// ggml's vectorised expf (vec.h:774-811, the AVX2+FMA flavour the reference CPU path runs for all
+// but the last n%8 softmax elements), restated in scalar form with the same operation order.
+__device__ __forceinline__ float wa_expf(float x) {
+    const float r = 0x1.8p23f;
+    const float z = fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    const float b = fmaf(-n, 0x1.7f7d1cp-20f, fmaf(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = __float_as_uint(z) << 23;
+    const float k = __uint_as_float(e + __float_as_uint(1.0f));
+    const float an = fabsf(n);
+    const float u = b * b;
+    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u,
+                         0x1.ffffecp-1f * b);
+    if (!(an > 126.0f)) return fmaf(j, k, k);
+    const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float s1 = __uint_as_float(g + 0x7f000000u);
+    const float s2 = __uint_as_float(e - g);
+    if (an > 192.0f) return s1 * s1;
+    return fmaf(s2, j, s2) * s1;
+}
+
+// GELU exactly as ggml_vec_gelu_f32 with GGML_GELU_FP16 (vec.h:571-585): table lookup on the F16
+// bits of x, identity above 10, zero below -10.  Result is an F32 that is exactly F16-representable
+// (or x itself for x >= 10).
+__device__ __forceinline__ float wa_gelu(float x, const wa_f16 * __restrict__ table) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >=  10.0f) return x;
+    return h2f(table[f2h(x)]);
+}
+
+// =================================================================================================
+// GEMM epilogues (shared by the MFMA GEMM and the GEMV)
+// =================================================================================================
+template <int EPI>
+__device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float acc) {
+    float v = acc;
+    if (EPI != WA_EPI_F32 || e.bias) { if (e.bias) v = v + e.bias[n]; }
+    if (EPI == WA_EPI_F16) {
+        if (e.scale) v = v * e.scale[n];
+        ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
+    } else if (EPI == WA_EPI_ENC_QKV) {
+        if (n < e.split0) ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
+        else              ((wa_f16 *) e.out2)[(size_t) (n - e.split0) * e.ldo2 + m] = f2h(v);
+    } else if (EPI == WA_EPI_GELU_F16) {
+        ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(wa_gelu(v, e.gelu));
+    } else if (EPI == WA_EPI_RESID) {
+        ((float *) e.out)[(size_t) m * e.ldo + n] = v + e.resid[(size_t) m * e.ldr + n];
+    } else if (EPI == WA_EPI_CONV2) {
+        const float g = wa_gelu(v, e.gelu);
+        if (e.dbg) e.dbg[(size_t) m * e.ldo + n] = g;
+        ((float *) e.out)[(size_t) m * e.ldo + n] = e.resid[(size_t) m * e.ldr + n] + g;
+    } else if (EPI == WA_EPI_F32) {
+        ((float *) e.out)[(size_t) m * e.ldo + n] = v;
+    } else if (EPI == WA_EPI_CROSS_KV) {
+        // n = layer*2d + kv*d + head*64 + c ; aux0 = tpad, aux1 = d
+        if (e.scale) v = v * e.scale[n];
+        const int d = e.aux1, two_d = 2 * d;
+        const int il = n / two_d, r = n - il * two_d;
+        const int kv = r >= d, rr = kv ? r - d : r;
+        const int n_head = d >> 6, hd = rr >> 6, c = rr & 63;
+        wa_f16 * dst = (wa_f16 *) (kv ? e.out2 : e.out);
+        dst[(((size_t) il * n_head + hd) * e.aux0 + m) * 64 + c] = f2h(v);
+    } else if (EPI == WA_EPI_DEC_QKV) {
+        if (e.scale) v = v * e.scale[n];
+        if (n < e.split0)      ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
+        else if (n < e.split1) ((wa_f16 *) e.out2)[(size_t) (e.row_off + m) * e.ldo2 + (n - e.split0)] = f2h(v);
+        else                   ((wa_f16 *) e.out3)[(size_t) (e.row_off + m) * e.ldo3 + (n - e.split1)] = f2h(v);
+    }
+}
+
+// =================================================================================================
+// MFMA GEMM: C = A * W^T, both operands K-contiguous F16, F32 accumulate (v_mfma_f32_16x16x32_f16).
+// Block = 256 threads = 4 waves in a 2x2 grid; block tile BM x BN x 32, wave tile (BM/2) x (BN/2).
+// LDS rows are padded to 40 halfs (80 B) so the 16-lane ds_read_b128 groups hit disjoint banks.
+// Roofline: MFMA-bound for the encoder shapes (AI ~ 1900 FLOP/B).
+// =================================================================================================
+#define GEMM_BK  32
+#define GEMM_LDS 40
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f16(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
+                                                  int M, int N, int K, wa_epi e) {
+    constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 tiles per wave in m / n
+    constexpr int CA = BM * 4 / 256, CB = BN * 4 / 256; // 16-byte chunks per thread per operand
+    __shared__ __attribute__((aligned(16))) wa_f16 As[2][BM * GEMM_LDS];
+    __shared__ __attribute__((aligned(16))) wa_f16 Bs[2][BN * GEMM_LDS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[CA], rb[CB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            int gm = m0 + row; gm = gm < M ? gm : M - 1;
+            ra[i] = *(const uint4 *) (A + (size_t) gm * lda + k0 + kc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            int gn = n0 + row; gn = gn < N ? gn : N - 1;
+            rb[i] = *(const uint4 *) (W + (size_t) gn * ldw + k0 + kc * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            *(uint4 *) (&As[buf][row * GEMM_LDS + kc * 8]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = c & 3;
+            *(uint4 *) (&Bs[buf][row * GEMM_LDS + kc * 8]) = rb[i];
+        }
+    };
+
+    const int nk = K / GEMM_BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * GEMM_BK);
+
+        half8 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[i] = *(const half8 *) (&As[buf][(wm * (BM / 2) + i * 16 + fr) * GEMM_LDS + fg * 8]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bf[j] = *(const half8 *) (&Bs[buf][(wn * (BN / 2) + j * 16 + fr) * GEMM_LDS + fg * 8]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C layout of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + fg * 4 + r;
+                if (m < M && n < N) epi_store<EPI>(e, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+template <int BM, int BN>
+static void gemm_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
+                          const wa_epi & e) {
+    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+#define WA_GEMM_CASE(E) case E: hipLaunchKernelGGL((k_gemm_f16<BM, BN, E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); break;
+    switch (mode) {
+        WA_GEMM_CASE(WA_EPI_F16)
+        WA_GEMM_CASE(WA_EPI_ENC_QKV)
+        WA_GEMM_CASE(WA_EPI_GELU_F16)
+        WA_GEMM_CASE(WA_EPI_RESID)
+        WA_GEMM_CASE(WA_EPI_CONV2)
+        WA_GEMM_CASE(WA_EPI_F32)
+        WA_GEMM_CASE(WA_EPI_CROSS_KV)
+        WA_GEMM_CASE(WA_EPI_DEC_QKV)
+    }
+#undef WA_GEMM_CASE
+}
+
+void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
+                    const wa_epi & e) {
+    // 128x128 tiles when that still yields >= 256 blocks (one per CU); 64x64 otherwise.
+    const long big = (long) ((M + 127) / 128) * ((N + 127) / 128);
+    if (big >= 256) gemm_dispatch<128, 128>(stream, mode, A, lda, W, ldw, M, N, K, e);
+    else            gemm_dispatch<64, 64>(stream, mode, A, lda, W, ldw, M, N, K, e);
+}
+
+// =================================================================================================
+// GEMV for the decode step (M <= 8 tokens): weight-streaming, HBM-bound.  One wave per output
+// column; the F16 activations are staged once per block in LDS; each lane streams 16-byte pieces of
+// the weight row straight into VGPRs (guide: "GEMV / M <= 16 decode weights ... neither LDS nor
+// glds"), dot products by v_dot2_f32_f16 (exact products, F32 accumulate).
+// =================================================================================================
+template <int MT, int EPI>
+__global__ __launch_bounds__(256) void k_gemv_f16(const wa_f16 * __restrict__ A, int lda, const int32_t * __restrict__ rows,
+                                                  const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
+    extern __shared__ __attribute__((aligned(16))) wa_f16 xs[];   // [MT][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kc = K >> 3;
+    for (int c = tid; c < MT * kc; c += 256) {
+        const int m = c / kc, cc = c - m * kc;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < M) {
+            const int src = rows ? rows[m] : m;
+            v = *(const uint4 *) (A + (size_t) src * lda + cc * 8);
+        }
+        *(uint4 *) (&xs[(size_t) m * K + cc * 8]) = v;
+    }
+    __syncthreads();
+
+    for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
+        const wa_f16 * wrow = W + (size_t) n * ldw;
+        float acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+        for (int c = lane; c < kc; c += 64) {
+            const uint4 wv = *(const uint4 *) (wrow + c * 8);
+            const half2v * w2 = (const half2v *) &wv;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const uint4 xv = *(const uint4 *) (&xs[(size_t) m * K + c * 8]);
+                const half2v * x2 = (const half2v *) &xv;
+                float a = acc[m];
+                a = __builtin_amdgcn_fdot2(w2[0], x2[0], a, false);
+                a = __builtin_amdgcn_fdot2(w2[1], x2[1], a, false);
+                a = __builtin_amdgcn_fdot2(w2[2], x2[2], a, false);
+                a = __builtin_amdgcn_fdot2(w2[3], x2[3], a, false);
+                acc[m] = a;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            if (lane == m && m < M) epi_store<EPI>(e, m, n, acc[m]);
+    }
+}
+
+template <int MT>
+static void gemv_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
+                          int M, int N, int K, const wa_epi & e) {
+    int grid = (N + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    const size_t lds = (size_t) MT * K * sizeof(wa_f16);
+#define WA_GEMV_CASE(E) case E: hipLaunchKernelGGL((k_gemv_f16<MT, E>), dim3(grid), dim3(256), lds, s, A, lda, rows, W, ldw, M, N, K, e); break;
+    switch (mode) {
+        WA_GEMV_CASE(WA_EPI_F16)
+        WA_GEMV_CASE(WA_EPI_GELU_F16)
+        WA_GEMV_CASE(WA_EPI_RESID)
+        WA_GEMV_CASE(WA_EPI_F32)
+        WA_GEMV_CASE(WA_EPI_DEC_QKV)
+        default: break;
+    }
+#undef WA_GEMV_CASE
+}
+
+static void gemv_any(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
+                     int M, int N, int K, const wa_epi & e) {
+    if (M <= 1)      gemv_dispatch<1>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+    else if (M <= 2) gemv_dispatch<2>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+    else if (M <= 4) gemv_dispatch<4>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+    else             gemv_dispatch<8>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+}
+
+void wa_launch_gemv(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
+                    const wa_epi & e) {
+    gemv_any(stream, mode, A, lda, nullptr, W, ldw, M, N, K, e);
+}
+
+void wa_launch_logits(hipStream_t stream, const wa_f16 * A, int lda, const int32_t * rows, int n_rows, const wa_f16 * W, int ldw,
+                      int N, int K, float * out) {
+    for (int r0 = 0; r0 < n_rows; r0 += 8) {
+        const int m = n_rows - r0 < 8 ? n_rows - r0 : 8;
+        wa_epi e;
+        e.out = out + (size_t) r0 * N; e.ldo = N;
+        gemv_any(stream, WA_EPI_F32, A, lda, rows ? rows + r0 : nullptr, W, ldw, m, N, K, e);
+    }
+}
+
+// =================================================================================================
+// log-mel spectrogram (whisper.cpp:3076-3276 restated for one workgroup per frame)
+//   frame -> Hann -> radix-2 decimation 400->200->100->50->25 with naive 25-point DFT leaves (same
+//   butterfly structure and table-driven twiddles as the reference, F32) -> power -> 80x201 filterbank
+//   accumulated in F64 from F32 4-term partial sums -> log10 -> F32.  Global max by ordered atomicMax,
+//   then clamp/scale in a second kernel (the reference's barrier between its two elementwise phases).
+// =================================================================================================
+__device__ __forceinline__ float pcm_padded(const float * __restrict__ pcm, int n, int p) {
+    // reflect 200 samples in front (whisper.cpp:3217), zeros behind (whisper.cpp:3214)
+    const int i = p < 200 ? 200 - p : p - 200;
+    return i < n ? pcm[i] : 0.0f;
+}
+
+__device__ __forceinline__ unsigned int f32_ordered(float f) {
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(unsigned int k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void k_mel_frames(const float * __restrict__ pcm, int n_samples, const float * __restrict__ hann,
+                                                    const float * __restrict__ sincos, const float * __restrict__ filters, int n_mel,
+                                                    int n_bins, float * __restrict__ mel, int n_len, int n_active,
+                                                    unsigned int * __restrict__ mel_max) {
+    __shared__ float xin[400];
+    __shared__ float2 bufA[400];
+    __shared__ float2 bufB[400];
+    __shared__ float pw[208];
+    __shared__ float s_sin[400], s_cos[400];
+    __shared__ float s_max[4];
+
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x;
+    const float neg10 = (float) -10.0;   // (float) log10(1e-10)  (whisper.cpp:3177)
+
+    if (frame >= n_active) {
+        for (int j = tid; j < n_mel; j += 256) mel[(size_t) j * n_len + frame] = neg10;
+        if (tid == 0) atomicMax(mel_max, f32_ordered(neg10));
+        return;
+    }
+
+    const int n_w = n_samples + 200;           // samples visible to the worker (whisper.cpp:3232)
+    const int offset = frame * 160;
+    for (int j = tid; j < 400; j += 256) {
+        s_sin[j] = sincos[j];
+        s_cos[j] = sincos[400 + j];
+        xin[j] = (offset + j < n_w) ? hann[j] * pcm_padded(pcm, n_samples, offset + j) : 0.0f;
+    }
+    __syncthreads();
+
+    // leaves: 16 DFTs of 25 points over x[o + 16 n]  (whisper.cpp:3054-3070)
+    for (int t = tid; t < 400; t += 256) {
+        const int o = t / 25, k = t - o * 25;
+        float re = 0.f, im = 0.f;
+        for (int n = 0; n < 25; ++n) {
+            const int idx = (k * n * 16) % 400;
+            const float v = xin[o + 16 * n];
+            re = fmaf(v, s_cos[idx], re);
+            im = fmaf(-v, s_sin[idx], im);
+        }
+        bufA[o * 25 + k] = make_float2(re, im);
+    }
+    __syncthreads();
+
+    // four radix-2 combine levels (whisper.cpp:3103-3117): node (o, s) <- even (o, 2s), odd (o + s, 2s)
+    float2 * src = bufA;
+    float2 * dst = bufB;
+#pragma unroll
+    for (int lvl = 0; lvl < 4; ++lvl) {
+        const int s = 8 >> lvl;              // stride of the node being produced: 8, 4, 2, 1
+        const int half_n = 25 << lvl;        // size of each child: 25, 50, 100, 200
+        if (tid < 200) {
+            const int o = tid / half_n, k = tid - o * half_n;
+            const float2 E = src[o * half_n + k];
+            const float2 O = src[(o + s) * half_n + k];
+            const int idx = k * s;
+            const float re = s_cos[idx], im = -s_sin[idx];
+            float2 lo, hi;
+            lo.x = fmaf(-im, O.y, fmaf(re, O.x, E.x));
+            lo.y = fmaf(im, O.x, fmaf(re, O.y, E.y));
+            hi.x = fmaf(im, O.y, fmaf(-re, O.x, E.x));
+            hi.y = fmaf(-im, O.x, fmaf(-re, O.y, E.y));
+            dst[o * 2 * half_n + k] = lo;
+            dst[o * 2 * half_n + k + half_n] = hi;
+        }
+        __syncthreads();
+        float2 * t2 = src; src = dst; dst = t2;
+    }
+    // after 4 swaps the spectrum is in `src`
+    if (tid < n_bins) {
+        const float2 v = src[tid];
+        pw[tid] = fmaf(v.y, v.y, v.x * v.x);
+    }
+    __syncthreads();
+
+    float lmax = -3.0e38f;
+    if (tid < n_mel) {
+        const float * f = filters + (size_t) tid * n_bins;
+        double sum = 0.0;
+        int k = 0;
+        for (; k < n_bins - 3; k += 4) {
+            float s4 = pw[k] * f[k];
+            s4 = fmaf(pw[k + 1], f[k + 1], s4);
+            s4 = fmaf(pw[k + 2], f[k + 2], s4);
+            s4 = fmaf(pw[k + 3], f[k + 3], s4);
+            sum += (double) s4;
+        }
+        for (; k < n_bins; ++k) sum += (double) (pw[k] * f[k]);
+        sum = log10(sum > 1e-10 ? sum : 1e-10);
+        const float out = (float) sum;
+        mel[(size_t) tid * n_len + frame] = out;
+        lmax = out;
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) s_max[tid >> 6] = lmax;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        atomicMax(mel_max, f32_ordered(m));
+    }
+}
+
+__global__ void k_mel_norm(float * __restrict__ mel, size_t n, const unsigned int * __restrict__ mel_max) {
+    const double mmax = (double) f32_unordered(*mel_max) - 8.0;         // whisper.cpp:3245-3252
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+        float v = mel[i];
+        if ((double) v < mmax) v = (float) mmax;
+        mel[i] = (float) (((double) v + 4.0) / 4.0);
+    }
+}
+
+void wa_launch_mel(hipStream_t stream, const float * pcm, int n_samples, const float * hann, const float * sincos,
+                   const float * filters, int n_mel, int n_fft_bins, float * mel, int n_len, unsigned int * mel_max) {
+    hipMemsetAsync(mel_max, 0, sizeof(unsigned int), stream);
+    int n_active = (n_samples + 200) / 160 + 1;
+    if (n_active > n_len) n_active = n_len;
+    hipLaunchKernelGGL(k_mel_frames, dim3(n_len), dim3(256), 0, stream, pcm, n_samples, hann, sincos, filters, n_mel, n_fft_bins, mel,
+                       n_len, n_active, mel_max);
+    const size_t n = (size_t) n_mel * n_len;
+    int grid = (int) ((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_mel_norm, dim3(grid), dim3(256), 0, stream, mel, n, mel_max);
+}
+
+// mel[n_mel][n_len] f32 -> melT[1 + t][ic] f16 for t in [0, n_frames); zero elsewhere (whisper.cpp:2399-2418)
+__global__ void k_mel_window(const float * __restrict__ mel, int n_mel, int n_len, int seek, int n_frames, wa_f16 * __restrict__ melT,
+                             int rows_total) {
+    const size_t total = (size_t) rows_total * n_mel;
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < total; i += (size_t) gridDim.x * blockDim.x) {
+        const int row = (int) (i / n_mel), ic = (int) (i - (size_t) row * n_mel);
+        const int t = row - 1;
+        float v = 0.0f;
+        if (t >= 0 && t < n_frames && seek + t < n_len) v = mel[(size_t) ic * n_len + seek + t];
+        melT[i] = f2h(v);
+    }
+}
+
+void wa_launch_mel_window(hipStream_t stream, const float * mel, int n_mel, int n_len, int seek, int n_frames, wa_f16 * melT,
+                          int rows_total) {
+    const size_t total = (size_t) rows_total * n_mel;
+    int grid = (int) ((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_mel_window, dim3(grid), dim3(256), 0, stream, mel, n_mel, n_len, seek, n_frames, melT, rows_total);
+}
+
+// =================================================================================================
+// LayerNorm (ops.cpp:3199-3248 + the separate mul / add of whisper.cpp:2121-2126): one wave per row.
+// mean and variance accumulate in F64 like ggml_float; the three elementwise steps round separately.
+// HBM-bound: reads d f32, writes d f16 (and optionally d f32).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
+                                                   const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
+                                                   float * __restrict__ out32, int ld32) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float * xr = x + (size_t) row * ldx;
+    double s = 0.0;
+    for (int i = lane; i < d; i += 64) s += (double) xr[i];
+    s = wave_sum_d(s);
+    const float mean = (float) (s / (double) d);
+    double s2 = 0.0;
+    for (int i = lane; i < d; i += 64) { const float v = xr[i] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum_d(s2);
+    const float variance = (float) (s2 / (double) d);
+    const float scale = 1.0f / sqrtf(variance + eps);
+    for (int i = lane; i < d; i += 64) {
+        float y = xr[i] - mean;
+        y = y * scale;
+        y = y * w[i];
+        y = y + b[i];
+        if (out16) out16[(size_t) row * ld16 + i] = f2h(y);
+        if (out32) out32[(size_t) row * ld32 + i] = y;
+    }
+}
+
+void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
+                         wa_f16 * out16, int ld16, float * out32, int ld32) {
+    hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32);
+}
+
+// =================================================================================================
+// Encoder self-attention, d_head = 64 (whisper.cpp:2181-2206 semantics):
+//   S = Q K^T (F16 operands, F32 acc) ; P = softmax(scale * S) in F32 over ALL keys ; P -> F16 ;
+//   O = P V (F16 operands, F32 acc) -> F16 (it is the next GEMM's A operand).
+// Two sweeps over the keys so that P is normalised BEFORE it is rounded to F16, as in the reference:
+// sweep 1 = running max / sum, sweep 2 = recompute S, normalise, round, P V.
+// Block = 4 waves x 16 query rows; K and V^T tiles of 64 keys staged in LDS (72-half rows:
+// conflict-free b128 reads); P crosses LDS once per tile (per-wave scratch).
+// =================================================================================================
+#define ATT_LD 72
+
+__global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk, int ldqk, const wa_f16 * __restrict__ vt, int ldvt, int T,
+                                                  int d, float scale, wa_f16 * __restrict__ out, int ldo) {
+    __shared__ __attribute__((aligned(16))) wa_f16 Ks[64 * ATT_LD];
+    __shared__ __attribute__((aligned(16))) wa_f16 Vs[64 * ATT_LD];
+    __shared__ __attribute__((aligned(16))) wa_f16 Ps[4][16 * ATT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+
+    // Q fragments: A operand, row = fr, k = dh
+    half8 qf[2];
+    {
+        int q = q0 + fr; q = q < T ? q : T - 1;
+        const wa_f16 * qp = qk + (size_t) q * ldqk + h * 64;
+        qf[0] = *(const half8 *) (qp + fg * 8);
+        qf[1] = *(const half8 *) (qp + 32 + fg * 8);
+    }
+
+    const int n_tiles = (T + 63) / 64;
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+
+    auto load_k = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+            int key = kt * 64 + row; key = key < T ? key : T - 1;
+            *(uint4 *) (&Ks[row * ATT_LD + kc * 8]) = *(const uint4 *) (qk + (size_t) key * ldqk + d + h * 64 + kc * 8);
+        }
+    };
+    auto load_v = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;   // row = dh, kc = key chunk
+            *(uint4 *) (&Vs[row * ATT_LD + kc * 8]) = *(const uint4 *) (vt + (size_t) (h * 64 + row) * ldvt + kt * 64 + kc * 8);
+        }
+    };
+    auto scores = [&](int kt, f32x4 (&s)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8 b = *(const half8 *) (&Ks[(nt * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[ks], b, a, 0, 0, 0);
+            }
+            const bool valid = kt * 64 + nt * 16 + fr < T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[nt][r] = valid ? a[r] * scale : -INFINITY;
+        }
+    };
+
+    // ---- sweep 1: row max and sum of exp ----
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        __syncthreads();
+        load_k(kt);
+        __syncthreads();
+        f32x4 s[4];
+        scores(kt, s);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
+            const float m_new = fmaxf(m_run[r], mx);
+            float ls = wa_expf(s[0][r] - m_new) + wa_expf(s[1][r] - m_new) + wa_expf(s[2][r] - m_new) + wa_expf(s[3][r] - m_new);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) ls += __shfl_xor(ls, o, WAVE);
+            const float corr = (m_run[r] == -INFINITY) ? 0.f : wa_expf(m_run[r] - m_new);
+            l_run[r] = l_run[r] * corr + ls;
+            m_run[r] = m_new;
+        }
+    }
+    float inv_l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) inv_l[r] = (float) (1.0 / (double) l_run[r]);   // ops.cpp:4815-4818
+
+    // ---- sweep 2: P = exp(s - m) / l -> F16 ; O += P V ----
+    f32x4 o_acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o_acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        __syncthreads();
+        load_k(kt);
+        load_v(kt);
+        __syncthreads();
+        f32x4 s[4];
+        scores(kt, s);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = wa_expf(s[nt][r] - m_run[r]) * inv_l[r];
+                Ps[wave][(fg * 4 + r) * ATT_LD + nt * 16 + fr] = f2h(p);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8 a = *(const half8 *) (&Ps[wave][fr * ATT_LD + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const half8 b = *(const half8 *) (&Vs[(j * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
+                o_acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, o_acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = q0 + fg * 4 + r;
+            if (q < T) out[(size_t) q * ldo + h * 64 + j * 16 + fr] = f2h(o_acc[j][r]);
+        }
+}
+
+void wa_launch_enc_attn(hipStream_t stream, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
+                        wa_f16 * out, int ldo) {
+    hipLaunchKernelGGL(k_enc_attn, dim3((T + 63) / 64, n_head), dim3(256), 0, stream, qk, ldqk, vt, ldvt, T, d, scale, out, ldo);
+}
+
+// =================================================================================================
+// decoder
+// =================================================================================================
+// x[j] = F32(token_embedding[tok]) + positional_embedding[pos]      (whisper.cpp:2531-2534)
+__global__ void k_dec_embed(const int32_t * __restrict__ tok, const int32_t * __restrict__ pos, int n_tokens, int d,
+                            const wa_f16 * __restrict__ te, const float * __restrict__ pe, float * __restrict__ x) {
+    const int j = blockIdx.x;
+    const int t = tok[j], p = pos[j];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(size_t) j * d + i] = h2f(te[(size_t) t * d + i]) + pe[(size_t) p * d + i];
+}
+
+void wa_launch_dec_embed(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d, const wa_f16 * te,
+                         const float * pe, float * x) {
+    hipLaunchKernelGGL(k_dec_embed, dim3(n_tokens), dim3(256), 0, stream, tok, pos, n_tokens, d, te, pe, x);
+}
+
+// One (token, head) per block: scores over n_kv keys (F16 q . F16 k, F32 acc) -> F32 softmax with
+// optional mask -> F16 probabilities -> P V (F32 acc) -> F16.  (whisper.cpp:2636-2651 / 2732-2758,
+// ops.cpp:4731-4827.)  The score row lives in a global scratch so n_kv is unbounded.
+// HBM/L2-bound on K and V (2 * n_kv * 128 B per block).
+__global__ __launch_bounds__(256) void k_dec_attn(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
+                                                  int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
+                                                  int n_kv, const int8_t * __restrict__ mask, float scale, float * __restrict__ scratch,
+                                                  int scratch_ld, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out) {
+    __shared__ float qs[64];
+    __shared__ float red[8];
+    __shared__ double redd[4];
+    __shared__ float part[4][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x, h = blockIdx.y, n_head = gridDim.y;
+    const wa_f16 * kp = kbase + (size_t) h * k_head_stride;
+    const wa_f16 * vp = vbase + (size_t) h * v_head_stride;
+    float * sc = scratch + ((size_t) j * n_head + h) * scratch_ld;
+    const int8_t * mrow = mask ? mask + (size_t) j * n_kv : nullptr;
+
+    if (tid < 64) qs[tid] = h2f(q[(size_t) j * ldq + h * 64 + tid]);
+    __syncthreads();
+
+    float lmax = -INFINITY;
+    for (int c = tid; c < n_kv; c += 256) {
+        const wa_f16 * kr = kp + (size_t) c * k_row_stride;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 kv = *(const uint4 *) (kr + i * 8);
+            const wa_f16 * k8 = (const wa_f16 *) &kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(h2f(k8[e]), qs[i * 8 + e], a);
+        }
+        a = a * scale;
+        if (mrow && mrow[c]) a = -INFINITY;
+        sc[c] = a;
+        lmax = fmaxf(lmax, a);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+
+    double lsum = 0.0;
+    for (int c = tid; c < n_kv; c += 256) {
+        const float e = wa_expf(sc[c] - mx);
+        sc[c] = e;
+        lsum += (double) e;
+    }
+    lsum = wave_sum_d(lsum);
+    if (lane == 0) redd[wave] = lsum;
+    __syncthreads();
+    const float inv = (float) (1.0 / (redd[0] + redd[1] + redd[2] + redd[3]));
+    for (int c = tid; c < n_kv; c += 256) {
+        const float p = sc[c] * inv;
+        if (qk_out) qk_out[((size_t) j * n_head + h) * n_kv + c] = p;
+        sc[c] = h2f(f2h(p));       // the P V product consumes F16 probabilities
+    }
+    __syncthreads();
+
+    float acc = 0.f;
+    for (int c = wave; c < n_kv; c += 4) acc = fmaf(sc[c], h2f(vp[(size_t) c * v_row_stride + lane]), acc);
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        const float o = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        out[(size_t) j * ldo + h * 64 + tid] = f2h(o);
+    }
+}
+
+void wa_launch_dec_self_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kcache, const wa_f16 * vcache, int d, int n_head,
+                             int n_tokens, int n_kv, const int8_t * mask, float * scores_scratch, wa_f16 * out, int ldo) {
+    hipLaunchKernelGGL(k_dec_attn, dim3(n_tokens, n_head), dim3(256), 0, stream, q, ldq, kcache, (size_t) 64, d, vcache, (size_t) 64, d,
+                       n_kv, mask, 1.0f, scores_scratch, n_kv, out, ldo, (float *) nullptr);
+}
+
+void wa_launch_dec_cross_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kc, const wa_f16 * vc, int tpad, int T,
+                              int n_head, int n_tokens, float scale, float * scores_scratch, wa_f16 * out, int ldo, float * qk_out) {
+    hipLaunchKernelGGL(k_dec_attn, dim3(n_tokens, n_head), dim3(256), 0, stream, q, ldq, kc, (size_t) tpad * 64, 64, vc, (size_t) tpad * 64,
+                       64, T, (const int8_t *) nullptr, scale, scores_scratch, T, out, ldo, qk_out);
+}

@@ -1,0 +1,379 @@
+// wa_loader.cpp - legacy-ggml model file parser -> HBM-resident weights.
+//
+// Format (ref: whisper.cpp:1503-1974 loader, models/convert-pt-to-ggml.py:266-340 writer):
+//   u32 magic 0x67676d6c | 11 x i32 hparams | i32 n_mel, i32 n_fft, f32 filters[n_mel*n_fft] |
+//   i32 n_vocab_file, (u32 len, bytes)* | tensor records (i32 n_dims, i32 name_len, i32 ttype,
+//   i32 ne[n_dims] fastest-first, name, raw data) until EOF.
+// Unlike the reference (one ggml tensor per record, generic layouts) the weights land in ONE device
+// arena in the layouts the kernels want:
+//   * encoder/decoder q,k,v fused into [3d][d] (+ bias / per-column scale vectors),
+//   * all decoder layers' cross-attention k,v fused into [L*2d][d] so the cross K/V of a chunk is
+//     ONE GEMM over the encoder output,
+//   * conv weights re-ordered k-major ([oc][k][ic]) so conv1/conv2 read the activations as a plain
+//     strided view (no im2col buffer), conv1's K padded to a multiple of 32 with zeros.
+#include "wa_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+template <typename T> bool rd(whisper_model_loader * l, T & v) { return l->read(l->context, &v, sizeof(T)) == sizeof(T); }
+
+inline float  h2f_host(wa_f16 h) { _Float16 v; memcpy(&v, &h, 2); return (float) v; }
+inline wa_f16 f2h_host(float f)  { _Float16 v = (_Float16) f; wa_f16 h; memcpy(&h, &v, 2); return h; }
+
+// ggml_gelu_f32 (vec.h:552-554) -> F16 table (ggml-cpu.c:3509-3517)
+inline float gelu_f32(float x) {
+    const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(SQRT_2_OVER_PI * x * (1.0f + GELU_COEF_A * x * x)));
+}
+
+struct slot {             // where a named tensor goes
+    int    kind;          // 0 raw copy, 1 conv weight re-order ([oc][ic][3] -> [oc][3][ic], row stride ld)
+    size_t off;           // byte offset in the arena
+    int    type;          // expected ggml type: 0 f32, 1 f16
+    int64_t ne[3];        // expected ne[] (fastest first)
+    int    ld;            // kind 1: destination row stride in elements
+    bool   seen = false;
+};
+
+struct arena_builder {
+    size_t size = 0;
+    size_t take(size_t bytes) { size_t o = size; size += (bytes + 255) & ~size_t(255); return o; }
+};
+
+} // namespace
+
+void wa_model_free(whisper_context & ctx) {
+    if (ctx.model.arena) { (void) hipFree(ctx.model.arena); ctx.model.arena = nullptr; }
+}
+
+bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
+    WA_INFO("%s: loading model\n", __func__);
+    const int64_t t_start = wa_time_us();
+    wctx.t_start_us = t_start;
+
+    auto & model = wctx.model;
+    auto & vocab = wctx.vocab;
+    auto & hp    = model.hp;
+
+    {   // magic
+        uint32_t magic = 0;
+        rd(loader, magic);
+        if (magic != 0x67676d6c) { WA_ERROR("%s: invalid model data (bad magic)\n", __func__); return false; }
+    }
+    {   // hparams, in file order (whisper.cpp:1527-1537)
+        int32_t * f[11] = { &hp.n_vocab, &hp.n_audio_ctx, &hp.n_audio_state, &hp.n_audio_head, &hp.n_audio_layer, &hp.n_text_ctx,
+                            &hp.n_text_state, &hp.n_text_head, &hp.n_text_layer, &hp.n_mels, &hp.ftype };
+        for (auto p : f) if (!rd(loader, *p)) { WA_ERROR("%s: truncated header\n", __func__); return false; }
+
+        model.type = 0;
+        switch (hp.n_audio_layer) { case 4: model.type = 1; break; case 6: model.type = 2; break; case 12: model.type = 3; break;
+                                    case 24: model.type = 4; break; case 32: model.type = 5; break; }
+        const int qntvr = hp.ftype / 1000;   // GGML_QNT_VERSION_FACTOR
+        hp.ftype %= 1000;
+        WA_INFO("%s: n_vocab       = %d\n", __func__, hp.n_vocab);
+        WA_INFO("%s: n_audio_ctx   = %d\n", __func__, hp.n_audio_ctx);
+        WA_INFO("%s: n_audio_state = %d\n", __func__, hp.n_audio_state);
+        WA_INFO("%s: n_audio_head  = %d\n", __func__, hp.n_audio_head);
+        WA_INFO("%s: n_audio_layer = %d\n", __func__, hp.n_audio_layer);
+        WA_INFO("%s: n_text_ctx    = %d\n", __func__, hp.n_text_ctx);
+        WA_INFO("%s: n_text_state  = %d\n", __func__, hp.n_text_state);
+        WA_INFO("%s: n_text_head   = %d\n", __func__, hp.n_text_head);
+        WA_INFO("%s: n_text_layer  = %d\n", __func__, hp.n_text_layer);
+        WA_INFO("%s: n_mels        = %d\n", __func__, hp.n_mels);
+        WA_INFO("%s: ftype         = %d\n", __func__, hp.ftype);
+        WA_INFO("%s: qntvr         = %d\n", __func__, qntvr);
+
+        if (hp.n_vocab <= 0 || hp.n_audio_ctx <= 0 || hp.n_audio_state <= 0 || hp.n_audio_head <= 0 || hp.n_audio_layer < 0 ||
+            hp.n_text_ctx <= 0 || hp.n_text_state <= 0 || hp.n_text_head <= 0 || hp.n_text_layer < 0 || hp.n_mels <= 0) {
+            WA_ERROR("%s: invalid model (bad hparams)\n", __func__);
+            return false;
+        }
+        if (hp.ftype != 1) {
+            // ftype 0 (all-F32) aborts in the reference's own conv path; quantised
+            // types are the "next" row and not built yet.
+            WA_ERROR("%s: unsupported ftype %d (this backend currently loads F16 models, ftype=1)\n", __func__, hp.ftype);
+            return false;
+        }
+    }
+    {   // mel filters
+        int32_t n_mel = 0, n_fft = 0;
+        rd(loader, n_mel); rd(loader, n_fft);
+        if (n_mel <= 0 || n_fft <= 0 || n_mel > 1024 || n_fft > 4096) { WA_ERROR("%s: invalid mel filter header\n", __func__); return false; }
+        model.n_mel_filt = n_mel; model.n_fft_filt = n_fft;
+        model.filters.resize((size_t) n_mel * n_fft);
+        loader->read(loader->context, model.filters.data(), model.filters.size() * sizeof(float));
+    }
+    {   // vocab (whisper.cpp:1607-1693)
+        int32_t n_vocab = 0;
+        rd(loader, n_vocab);
+        if (n_vocab < 0 || n_vocab > (1 << 24)) { WA_ERROR("%s: invalid vocab size\n", __func__); return false; }
+        vocab.id_to_token.assign(std::max(n_vocab, hp.n_vocab), std::string());
+        std::vector<char> tmp;
+        for (int i = 0; i < n_vocab; ++i) {
+            uint32_t len = 0;
+            rd(loader, len);
+            std::string word;
+            if (len > 0) {
+                if (len > (1u << 20)) { WA_ERROR("%s: invalid vocab entry\n", __func__); return false; }
+                tmp.resize(len);
+                loader->read(loader->context, tmp.data(), len);
+                word.assign(tmp.data(), len);
+            }
+            vocab.token_to_id[word] = i;
+            vocab.id_to_token[i] = word;
+        }
+        vocab.n_vocab = hp.n_vocab;
+        if (vocab.is_multilingual()) {
+            vocab.token_eot++; vocab.token_sot++;
+            const int dt = vocab.num_languages() - 98;
+            vocab.token_translate += dt; vocab.token_transcribe += dt; vocab.token_solm += dt; vocab.token_prev += dt;
+            vocab.token_nosp += dt; vocab.token_not += dt; vocab.token_beg += dt;
+        }
+        if (n_vocab < hp.n_vocab) {
+            WA_INFO("%s: adding %d extra tokens\n", __func__, hp.n_vocab - n_vocab);
+            for (int i = n_vocab; i < hp.n_vocab; ++i) {
+                std::string word;
+                if      (i >  vocab.token_beg)        word = "[_TT_" + std::to_string(i - vocab.token_beg) + "]";
+                else if (i == vocab.token_eot)        word = "[_EOT_]";
+                else if (i == vocab.token_sot)        word = "[_SOT_]";
+                else if (i == vocab.token_translate)  word = "[_TRANSLATE_]";
+                else if (i == vocab.token_transcribe) word = "[_TRANSCRIBE_]";
+                else if (i == vocab.token_solm)       word = "[_SOLM_]";
+                else if (i == vocab.token_prev)       word = "[_PREV_]";
+                else if (i == vocab.token_nosp)       word = "[_NOSP_]";
+                else if (i == vocab.token_not)        word = "[_NOT_]";
+                else if (i == vocab.token_beg)        word = "[_BEG_]";
+                else if (i > vocab.token_sot && i <= vocab.token_sot + vocab.num_languages()) {
+                    const char * ls = whisper_lang_str(i - vocab.token_sot - 1);
+                    word = "[_LANG_" + std::string(ls ? ls : "?") + "]";
+                } else word = "[_extra_token_" + std::to_string(i) + "]";
+                vocab.token_to_id[word] = i;
+                vocab.id_to_token[i] = word;
+            }
+        }
+        WA_INFO("%s: n_langs       = %d\n", __func__, vocab.num_languages());
+    }
+
+    const int d = hp.n_audio_state, Le = hp.n_audio_layer, Ld = hp.n_text_layer;
+    if (hp.n_text_state != d) { WA_ERROR("%s: n_text_state != n_audio_state is not supported\n", __func__); return false; }
+    if (d % 64 != 0 || d / hp.n_audio_head != 64 || d / hp.n_text_head != 64) {
+        WA_ERROR("%s: unsupported head size (kernels are built for d_head = 64, as in every Whisper model)\n", __func__);
+        return false;
+    }
+    if (model.n_mel_filt != hp.n_mels) { WA_ERROR("%s: mel filter count %d != n_mels %d\n", __func__, model.n_mel_filt, hp.n_mels); return false; }
+
+    // ---------------------------------------------------------------------------------------------
+    // arena plan
+    // ---------------------------------------------------------------------------------------------
+    arena_builder ab;
+    std::map<std::string, slot> slots;
+    auto add = [&](const std::string & name, int kind, size_t off, int type, int64_t n0, int64_t n1, int64_t n2, int ld = 0) {
+        slot s; s.kind = kind; s.off = off; s.type = type; s.ne[0] = n0; s.ne[1] = n1; s.ne[2] = n2; s.ld = ld;
+        slots[name] = s;
+    };
+    const size_t F = sizeof(float), H = sizeof(wa_f16);
+
+    const size_t o_filters = ab.take((size_t) model.n_mel_filt * model.n_fft_filt * F);
+    const size_t o_hann    = ab.take(400 * F);
+    const size_t o_sincos  = ab.take(800 * F);
+    const size_t o_gelu    = ab.take(65536 * H);
+
+    struct lin_off { size_t w, b, s; };
+    struct ln_off  { size_t w, b; };
+    auto take_ln = [&](const std::string & base) {
+        ln_off o{ ab.take(d * F), ab.take(d * F) };
+        add(base + ".weight", 0, o.w, 0, d, 1, 1);
+        add(base + ".bias",   0, o.b, 0, d, 1, 1);
+        return o;
+    };
+    auto take_lin = [&](const std::string & base, int n_out, int n_in) {
+        lin_off o{ ab.take((size_t) n_out * n_in * H), ab.take(n_out * F), 0 };
+        add(base + ".weight", 0, o.w, 1, n_in, n_out, 1);
+        add(base + ".bias",   0, o.b, 0, n_out, 1, 1);
+        return o;
+    };
+    // fused q|k|v block: [3d][d] weights + [3d] bias (+ [3d] scale, filled by us)
+    auto take_qkv = [&](const std::string & base, bool with_scale) {
+        lin_off o{ ab.take((size_t) 3 * d * d * H), ab.take(3 * d * F), with_scale ? ab.take(3 * d * F) : 0 };
+        add(base + ".query.weight", 0, o.w,                         1, d, d, 1);
+        add(base + ".key.weight",   0, o.w + (size_t) d * d * H,     1, d, d, 1);
+        add(base + ".value.weight", 0, o.w + (size_t) 2 * d * d * H, 1, d, d, 1);
+        add(base + ".query.bias",   0, o.b,             0, d, 1, 1);
+        add(base + ".value.bias",   0, o.b + 2 * d * F, 0, d, 1, 1);
+        return o;
+    };
+
+    const size_t o_epe = ab.take((size_t) hp.n_audio_ctx * d * F);
+    add("encoder.positional_embedding", 0, o_epe, 0, d, hp.n_audio_ctx, 1);
+    model.conv1_kpad = wa_pad(3 * hp.n_mels, 32);
+    const size_t o_c1w = ab.take((size_t) d * model.conv1_kpad * H), o_c1b = ab.take(d * F);
+    const size_t o_c2w = ab.take((size_t) d * 3 * d * H),            o_c2b = ab.take(d * F);
+    add("encoder.conv1.weight", 1, o_c1w, 1, 3, hp.n_mels, d, model.conv1_kpad);
+    add("encoder.conv1.bias",   0, o_c1b, 0, 1, d, 1);
+    add("encoder.conv2.weight", 1, o_c2w, 1, 3, d, d, 3 * d);
+    add("encoder.conv2.bias",   0, o_c2b, 0, 1, d, 1);
+    const ln_off o_eln = take_ln("encoder.ln_post");
+
+    struct enc_off { ln_off attn_ln, mlp_ln; lin_off qkv, out, fc1, fc2; };
+    std::vector<enc_off> eo(Le);
+    for (int i = 0; i < Le; ++i) {
+        const std::string p = "encoder.blocks." + std::to_string(i) + ".";
+        eo[i].attn_ln = take_ln(p + "attn_ln");
+        eo[i].qkv     = take_qkv(p + "attn", false);
+        eo[i].out     = take_lin(p + "attn.out", d, d);
+        eo[i].mlp_ln  = take_ln(p + "mlp_ln");
+        eo[i].fc1     = take_lin(p + "mlp.0", 4 * d, d);
+        eo[i].fc2     = take_lin(p + "mlp.2", d, 4 * d);
+    }
+
+    const size_t o_dpe = ab.take((size_t) hp.n_text_ctx * d * F);
+    const size_t o_dte = ab.take((size_t) hp.n_vocab * d * H);
+    add("decoder.positional_embedding",   0, o_dpe, 0, d, hp.n_text_ctx, 1);
+    add("decoder.token_embedding.weight", 0, o_dte, 1, d, hp.n_vocab, 1);
+    const ln_off o_dln = take_ln("decoder.ln");
+
+    // cross k|v of all layers fused: rows [il*2d, il*2d+d) key, [il*2d+d, (il+1)*2d) value
+    const size_t o_ckv_w = ab.take((size_t) Ld * 2 * d * d * H), o_ckv_b = ab.take((size_t) Ld * 2 * d * F),
+                 o_ckv_s = ab.take((size_t) Ld * 2 * d * F);
+
+    struct dec_off { ln_off attn_ln, cross_ln, mlp_ln; lin_off qkv, out, cq, cout, fc1, fc2; };
+    std::vector<dec_off> dof(Ld);
+    for (int i = 0; i < Ld; ++i) {
+        const std::string p = "decoder.blocks." + std::to_string(i) + ".";
+        dof[i].attn_ln  = take_ln(p + "attn_ln");
+        dof[i].qkv      = take_qkv(p + "attn", true);
+        dof[i].out      = take_lin(p + "attn.out", d, d);
+        dof[i].cross_ln = take_ln(p + "cross_attn_ln");
+        dof[i].cq       = take_lin(p + "cross_attn.query", d, d);
+        dof[i].cout     = take_lin(p + "cross_attn.out", d, d);
+        add(p + "cross_attn.key.weight",   0, o_ckv_w + ((size_t) i * 2 * d) * d * H,     1, d, d, 1);
+        add(p + "cross_attn.value.weight", 0, o_ckv_w + ((size_t) i * 2 * d + d) * d * H, 1, d, d, 1);
+        add(p + "cross_attn.value.bias",   0, o_ckv_b + ((size_t) i * 2 * d + d) * F,     0, d, 1, 1);
+        dof[i].mlp_ln   = take_ln(p + "mlp_ln");
+        dof[i].fc1      = take_lin(p + "mlp.0", 4 * d, d);
+        dof[i].fc2      = take_lin(p + "mlp.2", d, 4 * d);
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // host staging image of the arena
+    // ---------------------------------------------------------------------------------------------
+    std::vector<uint8_t> img;
+    try { img.assign(ab.size, 0); } catch (...) { WA_ERROR("%s: out of host memory for %zu bytes\n", __func__, ab.size); return false; }
+
+    memcpy(img.data() + o_filters, model.filters.data(), model.filters.size() * F);
+    {   // Hann window and sin/cos tables exactly as whisper.cpp:3031-3047 (float cosf/sinf of a double argument)
+        float * hann = (float *) (img.data() + o_hann);
+        float * sc   = (float *) (img.data() + o_sincos);
+        for (int i = 0; i < 400; ++i) {
+            hann[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / 400));
+            const double theta = (2 * M_PI * i) / 400;
+            sc[i]       = sinf(theta);
+            sc[400 + i] = cosf(theta);
+        }
+        wa_f16 * g = (wa_f16 *) (img.data() + o_gelu);
+        for (int i = 0; i < 65536; ++i) g[i] = f2h_host(gelu_f32(h2f_host((wa_f16) i)));
+    }
+    const float KQscale = pow(float(64), -0.25);   // whisper.cpp:2316, 2522
+    for (int i = 0; i < Ld; ++i) {
+        float * s = (float *) (img.data() + dof[i].qkv.s);
+        for (int c = 0; c < 3 * d; ++c) s[c] = c < 2 * d ? KQscale : 1.0f;
+        float * cs = (float *) (img.data() + o_ckv_s) + (size_t) i * 2 * d;
+        for (int c = 0; c < 2 * d; ++c) cs[c] = c < d ? KQscale : 1.0f;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // tensor records
+    // ---------------------------------------------------------------------------------------------
+    size_t total_size = 0;
+    model.n_loaded = 0;
+    std::vector<uint8_t> tmp;
+    while (true) {
+        int32_t n_dims = 0, length = 0, ttype = 0;
+        rd(loader, n_dims); rd(loader, length); rd(loader, ttype);
+        if (loader->eof(loader->context)) break;
+        if (n_dims < 1 || n_dims > 3 || length <= 0 || length > 256) { WA_ERROR("%s: corrupt tensor header\n", __func__); return false; }
+        int64_t ne[3] = { 1, 1, 1 };
+        int64_t nelements = 1;
+        for (int i = 0; i < n_dims; ++i) { int32_t v = 0; rd(loader, v); ne[i] = v; nelements *= v; }
+        std::string name(length, '\0');
+        loader->read(loader->context, &name[0], length);
+
+        auto it = slots.find(name);
+        if (it == slots.end()) { WA_ERROR("%s: unknown tensor '%s' in model file\n", __func__, name.c_str()); return false; }
+        slot & s = it->second;
+        if (nelements != s.ne[0] * s.ne[1] * s.ne[2]) { WA_ERROR("%s: tensor '%s' has wrong size in model file\n", __func__, name.c_str()); return false; }
+        if (ne[0] != s.ne[0] || ne[1] != s.ne[1] || ne[2] != s.ne[2]) {
+            WA_ERROR("%s: tensor '%s' has wrong shape in model file: got [%d, %d, %d], expected [%d, %d, %d]\n", __func__, name.c_str(),
+                     (int) ne[0], (int) ne[1], (int) ne[2], (int) s.ne[0], (int) s.ne[1], (int) s.ne[2]);
+            return false;
+        }
+        if (ttype != s.type) { WA_ERROR("%s: tensor '%s' has type %d in model file, expected %d\n", __func__, name.c_str(), ttype, s.type); return false; }
+        const size_t nbytes = (size_t) nelements * (s.type == 0 ? F : H);
+        if (s.kind == 0) {
+            if (loader->read(loader->context, img.data() + s.off, nbytes) != nbytes) { WA_ERROR("%s: truncated tensor '%s'\n", __func__, name.c_str()); return false; }
+        } else {
+            tmp.resize(nbytes);
+            if (loader->read(loader->context, tmp.data(), nbytes) != nbytes) { WA_ERROR("%s: truncated tensor '%s'\n", __func__, name.c_str()); return false; }
+            // file: [oc][ic][k] (k fastest) -> arena: [oc][k*IC + ic], row stride ld
+            const int IC = (int) s.ne[1], OC = (int) s.ne[2];
+            const wa_f16 * src = (const wa_f16 *) tmp.data();
+            wa_f16 * dst = (wa_f16 *) (img.data() + s.off);
+            for (int oc = 0; oc < OC; ++oc)
+                for (int ic = 0; ic < IC; ++ic)
+                    for (int k = 0; k < 3; ++k) dst[(size_t) oc * s.ld + k * IC + ic] = src[((size_t) oc * IC + ic) * 3 + k];
+        }
+        s.seen = true;
+        total_size += nbytes;
+        model.n_loaded++;
+    }
+    WA_INFO("%s: model size    = %7.2f MB\n", __func__, total_size / 1e6);
+    if (model.n_loaded == 0) {
+        WA_WARN("%s: WARN no tensors loaded from model file - assuming empty model for testing\n", __func__);
+    } else if (model.n_loaded != (int) slots.size()) {
+        WA_ERROR("%s: ERROR not all tensors loaded from model file - expected %zu, got %d\n", __func__, slots.size(), model.n_loaded);
+        return false;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // upload
+    // ---------------------------------------------------------------------------------------------
+    if (!WA_HIP_OK(hipSetDevice(wctx.device))) return false;
+    if (!WA_HIP_OK(hipMalloc(&model.arena, ab.size))) return false;
+    model.arena_size = ab.size;
+    if (!WA_HIP_OK(hipMemcpy(model.arena, img.data(), ab.size, hipMemcpyHostToDevice))) return false;
+    WA_INFO("%s: %12s total size = %8.2f MB\n", __func__, "HIP0", ab.size / 1e6);
+
+    uint8_t * base = (uint8_t *) model.arena;
+    auto PF = [&](size_t o) { return (const float *) (base + o); };
+    auto PH = [&](size_t o) { return (const wa_f16 *) (base + o); };
+    auto LN = [&](ln_off o) { wa_ln r; r.w = PF(o.w); r.b = PF(o.b); return r; };
+    auto LIN = [&](lin_off o, int n_out, int n_in) { wa_lin r; r.w = PH(o.w); r.b = PF(o.b); r.s = o.s ? PF(o.s) : nullptr; r.n_out = n_out; r.n_in = n_in; return r; };
+
+    model.d_filters = PF(o_filters); model.d_hann = PF(o_hann); model.d_sincos = PF(o_sincos); model.d_gelu = PH(o_gelu);
+    model.e_pe = PF(o_epe);
+    model.conv1 = LIN(lin_off{ o_c1w, o_c1b, 0 }, d, model.conv1_kpad);
+    model.conv2 = LIN(lin_off{ o_c2w, o_c2b, 0 }, d, 3 * d);
+    model.e_ln = LN(o_eln);
+    model.enc.resize(Le);
+    for (int i = 0; i < Le; ++i) {
+        model.enc[i].attn_ln = LN(eo[i].attn_ln); model.enc[i].mlp_ln = LN(eo[i].mlp_ln);
+        model.enc[i].qkv = LIN(eo[i].qkv, 3 * d, d);  model.enc[i].out = LIN(eo[i].out, d, d);
+        model.enc[i].fc1 = LIN(eo[i].fc1, 4 * d, d);  model.enc[i].fc2 = LIN(eo[i].fc2, d, 4 * d);
+    }
+    model.d_pe = PF(o_dpe); model.d_te = PH(o_dte); model.d_ln = LN(o_dln);
+    model.dec.resize(Ld);
+    for (int i = 0; i < Ld; ++i) {
+        auto & L = model.dec[i];
+        L.attn_ln = LN(dof[i].attn_ln); L.cross_ln = LN(dof[i].cross_ln); L.mlp_ln = LN(dof[i].mlp_ln);
+        L.qkv = LIN(dof[i].qkv, 3 * d, d); L.out = LIN(dof[i].out, d, d);
+        L.cross_q = LIN(dof[i].cq, d, d);  L.cross_out = LIN(dof[i].cout, d, d);
+        L.fc1 = LIN(dof[i].fc1, 4 * d, d); L.fc2 = LIN(dof[i].fc2, d, 4 * d);
+    }
+    model.cross_kv = LIN(lin_off{ o_ckv_w, o_ckv_b, o_ckv_s }, Ld * 2 * d, d);
+
+    wctx.t_load_us = wa_time_us() - t_start;
+    return true;
+}
