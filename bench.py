@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the Whisper hot path on MI355X (contract: see the task brief).
+
+Metric (BASELINE.json): real-time factor = audio-seconds / wall-seconds of `WhisperState::full`
+(`whisper_full_with_state`) on 30 s, 16 kHz mono f32 chunks, ggml-small-shaped model, greedy decoding.
+A "step" = one full() over one batch of synthetic chunks (default one 30 s chunk per GPU), PCM already
+resident in HBM when the timed region starts.  N > 1: one process per GPU, independent chunks per rank
+(no collective in the data path; weak scaling), barrier + max over ranks around the timed region.
+
+Extra objects on the JSON line:
+  roofline     - the decode step (dominant by time): HBM-bound; achieved = algorithmic bytes per decode
+                 step (weights + cross K/V + self K/V) / device time per step measured with
+                 HIP events on the state's stream (whisper_amd_decode_step_probe).
+  encoder      - encoder ms per 30 s chunk + fraction of the dense F16 MFMA peak (second half of the metric).
+  cpu_baseline - the reference engine itself (oracle/_ref, kind "reference") timed on this box's host
+                 cores on the same chunk, same parameters (bounded: one chunk, token count capped).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "whisper-rust_amd"))
+
+import numpy as np  # noqa: E402
+import wsynth  # noqa: E402
+import whisper_rs as W  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0
+
+
+def encoder_flops(shape):
+    d, Le, Ld, n_mels, T = shape["d"], shape["enc"], shape["dec"], shape["n_mels"], 1500
+    return 2 * d * n_mels * 3 * 3000 + 2 * d * d * 3 * 1500 + Le * (8 * T * d * d + 4 * T * T * d + 16 * T * d * d) + Ld * 4 * T * d * d
+
+
+def decode_bytes(shape, n_past):
+    d, Ld, nv, T = shape["d"], shape["dec"], shape["n_vocab"], 1500
+    return 2 * (14 * Ld * d * d + nv * d) + 4 * Ld * T * d + 4 * Ld * d * n_past
+
+
+class Hip:
+    """The few HIP runtime calls the bench needs (device buffers for resident PCM, sync)."""
+
+    def __init__(self):
+        self.lib = C.CDLL("libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.lib.hipFree.argtypes = [C.c_void_p]
+
+    def check(self, r, what):
+        if r != 0:
+            raise RuntimeError("%s failed with hipError %d" % (what, r))
+
+    def set_device(self, i):
+        self.check(self.lib.hipSetDevice(i), "hipSetDevice")
+
+    def to_device(self, arr):
+        p = C.c_void_p()
+        self.check(self.lib.hipMalloc(C.byref(p), arr.nbytes), "hipMalloc")
+        self.check(self.lib.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1), "hipMemcpy")
+        return p.value
+
+    def sync(self):
+        self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="small", choices=list(wsynth.SHAPES))
+    ap.add_argument("--chunks-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flash-attn", type=int, default=1, help="1 = MFMA fast path (default), 0 = reference-order path")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    hip = Hip()
+    hip.set_device(local_rank)
+    lib = W.load_library()          # fails loudly if the HIP library is missing
+    W.set_log_callback(lib, lambda lvl, txt: sys.stderr.write(txt) if lvl >= 3 else None)
+    shape = wsynth.SHAPES[args.model]
+
+    # ---- weights: rank 0 owns the file image; other ranks receive it over RCCL/xGMI (no per-rank disk read)
+    if rank == 0:
+        mp = wsynth.model_path(args.model)
+    if world > 1:
+        import torch
+        if rank == 0:
+            img = torch.from_numpy(np.fromfile(mp, dtype=np.uint8)).cuda()
+            n = torch.tensor([img.numel()], dtype=torch.int64, device="cuda")
+        else:
+            n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        dist.broadcast(n, 0)
+        if rank != 0:
+            img = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(img, 0)
+        buf = img.cpu().numpy().tobytes()
+        ctx = W.WhisperContext.new_from_buffer_with_params(
+            buf, W.WhisperContextParameters(lib, gpu_device=local_rank, flash_attn=bool(args.flash_attn)), lib=lib)
+        del img, buf
+    else:
+        ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib, gpu_device=local_rank, flash_attn=bool(args.flash_attn)), lib=lib)
+
+    n_chunks = args.chunks_per_gpu
+    states = [ctx.create_state() for _ in range(n_chunks)]
+    pcm_host = [wsynth.synth_audio(480000, rank * n_chunks + i) for i in range(n_chunks)]
+    pcm_dev = [hip.to_device(p) for p in pcm_host]
+    fp = W.FullParams(lib, best_of=1, temperature_inc=0.0, language="en", no_context=True)
+
+    def step():
+        ntok = 0
+        for st, dp in zip(states, pcm_dev):
+            st.full(fp, (dp, 480000))
+            ntok += sum(st.full_n_tokens(i) for i in range(st.full_n_segments()))
+        return ntok
+
+    for _ in range(args.warmup):
+        step()
+    hip.sync()
+    barrier()
+    t0 = time.perf_counter()
+    ntok = 0
+    for _ in range(args.steps):
+        ntok = step()
+    hip.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tk = torch.tensor([ntok], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tk)
+        ntok_all = int(tk.item())
+    else:
+        ntok_all = ntok
+
+    audio_s = 30.0 * n_chunks * world * args.steps
+    rtf = audio_s / dt
+    out = {
+        "metric": "real-time factor (audio-sec/wall-sec), greedy, 30 s synthetic chunks",
+        "value": round(rtf, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16 operands / f32 accumulate", "data": "synthetic",
+        "config": {"workload": "ggml-%s-shaped synthetic F16 model, greedy best_of=1 temperature_inc=0, %d x 30 s 16 kHz f32 chunk per GPU, PCM resident in HBM"
+                               % (args.model, n_chunks),
+                   "tokens_decoded_per_step": ntok_all, "flash_attn": bool(args.flash_attn), "parallelism": "chunk-dp%d" % world},
+    }
+
+    if rank == 0:
+        # ---- stage timings of the last step (per-state counters) + roofline probes
+        tm = (C.c_int64 * 12)()
+        lib.whisper_amd_get_timings_us.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        lib.whisper_amd_reset_timings.argtypes = [C.c_void_p]
+        st = states[0]
+        lib.whisper_amd_reset_timings(st.ptr)
+        st.full(fp, (pcm_dev[0], 480000))
+        lib.whisper_amd_get_timings_us(st.ptr, tm)
+        t_sample, t_encode, t_decode, t_batchd, t_prompt, t_mel, n_sample, n_encode, n_decode = [int(x) for x in tm[:9]]
+        enc_ms = 1e-3 * t_encode / max(1, n_encode)
+        dec_ms_wall = 1e-3 * t_decode / max(1, n_decode)
+        ms = C.c_float()
+        lib.whisper_amd_decode_step_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        n_past = 64
+        rc = lib.whisper_amd_decode_step_probe(ctx.ptr, st.ptr, n_past, 200, C.byref(ms))
+        dbytes = decode_bytes(shape, n_past)
+        if rc == 0 and ms.value > 0:
+            gbs = dbytes / (ms.value * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "decode step (GEMV chain k_gemv_f16 + attention), 1 token",
+                               "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                               "traffic": None, "bytes_per_step": dbytes, "ms_per_step_device": round(ms.value, 4),
+                               "ms_per_token_wall_in_full": round(dec_ms_wall, 4)}
+        eflops = encoder_flops(shape)
+        out["encoder"] = {"ms_per_30s_chunk": round(enc_ms, 3), "gflop": round(eflops / 1e9, 1),
+                          "achieved_tflops": round(eflops / (enc_ms * 1e-3) / 1e12, 1) if enc_ms > 0 else None,
+                          "peak_tflops": MFMA_F16_PEAK_TFLOPS,
+                          "frac": round(eflops / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if enc_ms > 0 else None,
+                          "mel_ms": round(1e-3 * t_mel, 3), "sample_ms_per_token": round(1e-3 * t_sample / max(1, n_sample), 4)}
+
+        # ---- CPU baseline: the reference engine on this box's host cores (rank 0, N == 1 only)
+        ref_path = os.path.join(ROOT, "oracle", "_ref", "libwhisper_ref.so")
+        if world == 1 and not args.no_cpu_baseline and os.path.exists(ref_path):
+            ref = W.load_library(ref_path)
+            W.set_log_callback(ref, None)
+            cores = os.cpu_count() or 1
+            nthr = min(cores, 64)
+            rctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(ref, use_gpu=False), lib=ref)
+            rst = rctx.create_state()
+            rfp = W.FullParams(ref, best_of=1, temperature_inc=0.0, language="en", no_context=True, n_threads=nthr)
+            t1 = time.perf_counter()
+            rst.full(rfp, pcm_host[0])
+            rdt = time.perf_counter() - t1
+            rtok = sum(rst.full_n_tokens(i) for i in range(rst.full_n_segments()))
+            same = [s["ids"] for s in rst.segments()] == [s["ids"] for s in states[0].segments()]
+            out["cpu_baseline"] = {"value": round(30.0 / rdt, 3), "unit": "x real-time", "cores": nthr, "kind": "reference",
+                                   "sample": "one 30 s chunk (seed 0), same model file and FullParams, plain ggml-cpu AVX2 build (OpenBLAS absent), %d tokens, %.2f s"
+                                             % (rtok, rdt),
+                                   "token_ids_identical_to_gpu": bool(same)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -455,6 +455,11 @@ WHISPER_API void whisper_amd_gelu_table_f16(uint16_t * dst);
  * event timing (bench.py) and stream-ordered hand-off of device PCM buffers. */
 WHISPER_API void * whisper_amd_state_stream(struct whisper_state * state);
 
+/* Measurement helper (bench.py): replays the single-token decoder pass `n_iters` times back to back on the
+ * state's stream between two HIP events and returns the average DEVICE time of one decode step in ms.
+ * Needs a prior whisper_encode*; touches KV cell `n_past` of the state.  0 on success. */
+WHISPER_API int whisper_amd_decode_step_probe(struct whisper_context * ctx, struct whisper_state * state, int n_past, int n_iters, float * ms_per_step);
+
 /* Batched chunk-parallel transcription on ONE device: runs `n_chunks` independent
  * whisper_full_with_state jobs, each on its own state, decoding them in lock-step so that one
  * pass over the decoder weights serves all live chunks.  samples[i] may be host or device pointers.

@@ -79,54 +79,17 @@ static void linear(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, c
     else        wa_launch_gemm(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
 }
 
-bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads, ggml_abort_callback abort_cb,
-               void * abort_data) {
-    const int64_t t0 = wa_time_us();
+// Pure launch sequence of one decoder pass (no host synchronisation, no KV metadata): tokens/positions/
+// rows/mask are already in d_tok/d_pos/d_rows/d_mask.  `mask` may be null (every cell < n_kv visible).
+static void decode_launch(whisper_context & ctx, whisper_state & st, int n_tokens, int n_kv, int kv_head, const int8_t * mask, int n_rows,
+                          bool save_aheads) {
     const auto & m  = ctx.model;
     const auto & hp = m.hp;
-    const int n_vocab = hp.n_vocab, n_tokens = batch.n_tokens;
-    if (n_tokens <= 0 || n_tokens > st.dec_mpad) { WA_ERROR("%s: bad batch size %d\n", __func__, n_tokens); return false; }
-    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
-
     auto & kv = st.kv_self;
-    if (!wa_kv_find_slot(kv, batch)) return false;
-    kv.n = std::min(kv.size, (uint32_t) std::max(1, wa_kv_cell_max(kv)));     // padding = 1 (whisper.cpp:2892-2893)
-    const int n_kv = kv.n, kv_head = kv.head;
-
-    st.logits.resize((size_t) n_tokens * n_vocab);
-    if (m.n_loaded == 0) {          // header-only test model
-        std::fill(st.logits.begin(), st.logits.end(), 0.0f);
-        return !(abort_cb && abort_cb(abort_data));
-    }
-
+    const int n_vocab = hp.n_vocab;
     const int d = hp.n_text_state, H = hp.n_text_head;
     const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
     hipStream_t s = st.stream;
-
-    // ---- inputs: tokens, positions, rows that need logits, KQ mask (whisper.cpp:2912-2956) ----
-    int32_t * h_tok = st.h_stage_i32, * h_pos = h_tok + st.dec_mpad, * h_rows = h_pos + st.dec_mpad;
-    int n_rows = 0;
-    for (int i = 0; i < n_tokens; ++i) {
-        h_tok[i] = batch.token[i];
-        h_pos[i] = batch.pos[i];
-        if (batch.logits[i]) h_rows[n_rows++] = i;
-    }
-    if (n_rows > WA_MAX_DECODERS) { WA_ERROR("%s: too many logits rows requested (%d)\n", __func__, n_rows); return false; }
-    for (int i = 0; i < n_tokens; ++i)
-        if (h_tok[i] < 0 || h_tok[i] >= n_vocab || h_pos[i] < 0 || h_pos[i] >= hp.n_text_ctx) {
-            WA_ERROR("%s: token %d / position %d out of range\n", __func__, h_tok[i], h_pos[i]);
-            return false;
-        }
-    if ((size_t) n_tokens * n_kv > st.h_mask_cap) { WA_ERROR("%s: mask overflow\n", __func__); return false; }
-    int8_t * h_mask = st.h_stage_mask;
-    for (int j = 0; j < n_tokens; ++j) {
-        const int32_t pos = batch.pos[j], seq = batch.seq_id[j];
-        for (int i = 0; i < n_kv; ++i) h_mask[(size_t) j * n_kv + i] = (!kv.cells[i].has(seq) || kv.cells[i].pos > pos) ? 1 : 0;
-    }
-    (void) hipMemcpyAsync(st.d_tok,  h_tok,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    (void) hipMemcpyAsync(st.d_pos,  h_pos,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    if (n_rows) (void) hipMemcpyAsync(st.d_rows, h_rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
 
     wa_launch_dec_embed(s, st.d_tok, st.d_pos, n_tokens, d, m.d_te, m.d_pe, st.d_dx);
 
@@ -144,7 +107,7 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
             e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
             linear(s, WA_EPI_DEC_QKV, st.d_dxn, d, L.qkv, n_tokens, e);
         }
-        wa_launch_dec_self_attn(s, st.d_dq, d, kv.k + il * kv_layer, kv.v + il * kv_layer, d, H, n_tokens, n_kv, st.d_mask, st.d_scores,
+        wa_launch_dec_self_attn(s, st.d_dq, d, kv.k + il * kv_layer, kv.v + il * kv_layer, d, H, n_tokens, n_kv, mask, st.d_scores,
                                 st.d_dao, d);
         {
             wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
@@ -182,8 +145,58 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     // copies out the flagged ones, whisper.cpp:2835, 2965-2971)
     if (n_rows) {
         wa_launch_logits(s, st.d_dxn, d, st.d_rows, n_rows, m.d_te, d, n_vocab, d, st.d_logits);
-        (void) hipMemcpyAsync(st.h_logits_pinned, st.d_logits, (size_t) n_rows * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     }
+}
+
+bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads, ggml_abort_callback abort_cb,
+               void * abort_data) {
+    const int64_t t0 = wa_time_us();
+    const auto & m  = ctx.model;
+    const auto & hp = m.hp;
+    const int n_vocab = hp.n_vocab, n_tokens = batch.n_tokens;
+    if (n_tokens <= 0 || n_tokens > st.dec_mpad) { WA_ERROR("%s: bad batch size %d\n", __func__, n_tokens); return false; }
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
+
+    auto & kv = st.kv_self;
+    if (!wa_kv_find_slot(kv, batch)) return false;
+    kv.n = std::min(kv.size, (uint32_t) std::max(1, wa_kv_cell_max(kv)));     // padding = 1 (whisper.cpp:2892-2893)
+    const int n_kv = kv.n, kv_head = kv.head;
+
+    st.logits.resize((size_t) n_tokens * n_vocab);
+    if (m.n_loaded == 0) {          // header-only test model
+        std::fill(st.logits.begin(), st.logits.end(), 0.0f);
+        return !(abort_cb && abort_cb(abort_data));
+    }
+
+    hipStream_t s = st.stream;
+
+    // ---- inputs: tokens, positions, rows that need logits, KQ mask (whisper.cpp:2912-2956) ----
+    int32_t * h_tok = st.h_stage_i32, * h_pos = h_tok + st.dec_mpad, * h_rows = h_pos + st.dec_mpad;
+    int n_rows = 0;
+    for (int i = 0; i < n_tokens; ++i) {
+        h_tok[i] = batch.token[i];
+        h_pos[i] = batch.pos[i];
+        if (batch.logits[i]) h_rows[n_rows++] = i;
+    }
+    if (n_rows > WA_MAX_DECODERS) { WA_ERROR("%s: too many logits rows requested (%d)\n", __func__, n_rows); return false; }
+    for (int i = 0; i < n_tokens; ++i)
+        if (h_tok[i] < 0 || h_tok[i] >= n_vocab || h_pos[i] < 0 || h_pos[i] >= hp.n_text_ctx) {
+            WA_ERROR("%s: token %d / position %d out of range\n", __func__, h_tok[i], h_pos[i]);
+            return false;
+        }
+    if ((size_t) n_tokens * n_kv > st.h_mask_cap) { WA_ERROR("%s: mask overflow\n", __func__); return false; }
+    int8_t * h_mask = st.h_stage_mask;
+    for (int j = 0; j < n_tokens; ++j) {
+        const int32_t pos = batch.pos[j], seq = batch.seq_id[j];
+        for (int i = 0; i < n_kv; ++i) h_mask[(size_t) j * n_kv + i] = (!kv.cells[i].has(seq) || kv.cells[i].pos > pos) ? 1 : 0;
+    }
+    (void) hipMemcpyAsync(st.d_tok,  h_tok,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    (void) hipMemcpyAsync(st.d_pos,  h_pos,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (n_rows) (void) hipMemcpyAsync(st.d_rows, h_rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
+
+    decode_launch(ctx, st, n_tokens, n_kv, kv_head, st.d_mask, n_rows, save_aheads);
+    if (n_rows) (void) hipMemcpyAsync(st.h_logits_pinned, st.d_logits, (size_t) n_rows * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
     for (int r = 0; r < n_rows; ++r)
         memcpy(st.logits.data() + (size_t) h_rows[r] * n_vocab, st.h_logits_pinned + (size_t) r * n_vocab, n_vocab * sizeof(float));
@@ -193,4 +206,36 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     else if (n_tokens < 16)  { st.t_batchd_us += dt; st.n_batchd += n_tokens; }
     else                     { st.t_prompt_us += dt; st.n_prompt += n_tokens; }
     return !(abort_cb && abort_cb(abort_data));
+}
+
+// -------------------------------------------------------------------------------------------------
+// measurement helper: replay the single-token decoder pass `n_iters` times back to back on the state's
+// stream between two HIP events (no host work in between) -> average device time of ONE decode step.
+// Used by bench.py for the HBM roofline of the decode step.  Uses KV cells [0, n_past]
+// of sequence 0 and leaves the cell metadata untouched.
+// -------------------------------------------------------------------------------------------------
+extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struct whisper_state * st, int n_past, int n_iters, float * ms_per_step) {
+    if (!ctx || !st || !ms_per_step || n_iters <= 0 || ctx->model.n_loaded == 0) return -1;
+    if (n_past < 0 || n_past + 1 > (int) st->kv_self.size || n_past >= ctx->model.hp.n_text_ctx) return -1;
+    if (!WA_HIP_OK(hipSetDevice(ctx->device))) return -1;
+    hipStream_t s = st->stream;
+    int32_t * h = st->h_stage_i32;
+    h[0] = ctx->vocab.token_eot > 100 ? 100 : 0;   // any valid token
+    h[1] = n_past;
+    h[2] = 0;
+    (void) hipMemcpyAsync(st->d_tok,  h,     sizeof(int32_t), hipMemcpyHostToDevice, s);
+    (void) hipMemcpyAsync(st->d_pos,  h + 1, sizeof(int32_t), hipMemcpyHostToDevice, s);
+    (void) hipMemcpyAsync(st->d_rows, h + 2, sizeof(int32_t), hipMemcpyHostToDevice, s);
+    hipEvent_t e0, e1;
+    if (!WA_HIP_OK(hipEventCreate(&e0)) || !WA_HIP_OK(hipEventCreate(&e1))) return -1;
+    decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false);      // warm-up
+    (void) hipEventRecord(e0, s);
+    for (int i = 0; i < n_iters; ++i) decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false);
+    (void) hipEventRecord(e1, s);
+    if (!WA_HIP_OK(hipEventSynchronize(e1))) return -1;
+    float ms = 0.f;
+    (void) hipEventElapsedTime(&ms, e0, e1);
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    *ms_per_step = ms / n_iters;
+    return 0;
 }

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void k_mel_frames(const float * __restrict__ p
     // after 4 swaps the spectrum is in `src`
     if (tid < n_bins) {
         const float2 v = src[tid];
-        pw[tid] = fmaf(v.y, v.y, v.x * v.x);
+        pw[tid] = fmaf(v.x, v.x, v.y * v.y);   // gcc's contraction in the reference build: fma(re, re, im*im)
     }
     __syncthreads();
 
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256) void k_mel_frames(const float * __restrict__ p
         double sum = 0.0;
         int k = 0;
         for (; k < n_bins - 3; k += 4) {
-            float s4 = pw[k] * f[k];
-            s4 = fmaf(pw[k + 1], f[k + 1], s4);
+            float s4 = pw[k + 1] * f[k + 1];          // order of the reference build's contraction:
+            s4 = fmaf(pw[k], f[k], s4);               // ((p1 f1 + p0 f0) + p2 f2) + p3 f3
             s4 = fmaf(pw[k + 2], f[k + 2], s4);
             s4 = fmaf(pw[k + 3], f[k + 3], s4);
             sum += (double) s4;
