@@ -154,6 +154,7 @@ whisper_context * init_common(whisper_model_loader * loader, whisper_context_par
     whisper_context * ctx = new whisper_context;
     ctx->params = params;
     ctx->device = params.gpu_device;
+    ctx->exact = !params.flash_attn;   // flash_attn trades the reference's summation order for MFMA speed, as it does in the reference
     bool ok = false;
     try { ok = wa_model_load(loader, *ctx); } catch (const std::exception & e) { WA_ERROR("%s: exception: %s\n", __func__, e.what()); ok = false; }
     loader->close(loader->context);

@@ -73,10 +73,12 @@ void wa_kv_seq_cp(wa_kv_cache & c, int32_t src, int32_t dst, int32_t p0, int32_t
 // -------------------------------------------------------------------------------------------------
 // decoder pass
 // -------------------------------------------------------------------------------------------------
-// small-M products stream the weights once (GEMV, HBM-bound); larger M (prompt) goes to the MFMA GEMM
-static void linear(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
-    if (M <= 8) wa_launch_gemv(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
-    else        wa_launch_gemm(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
+// small-M products stream the weights once (GEMV, HBM-bound, reference summation order);
+// larger M (prompt): reference-order VALU GEMM, or the MFMA GEMM when flash_attn is on
+static void linear(hipStream_t s, bool exact, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
+    if (M <= 8)     wa_launch_gemv_exact(s, mode, A, lda, nullptr, L.w, L.n_in, M, L.n_out, L.n_in, e);   // reference order is free here
+    else if (exact) wa_launch_gemm_exact(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
+    else            wa_launch_gemm(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
 }
 
 // Pure launch sequence of one decoder pass (no host synchronisation, no KV metadata): tokens/positions/
@@ -100,51 +102,52 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
     for (int il = 0; il < hp.n_text_layer; ++il) {
         const auto & L = m.dec[il];
         // ---- masked self-attention ----
-        wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
         {   // fused q|k|v: q scaled -> d_dq ; k scaled, v -> straight into their KV cells [kv_head, kv_head + n_tokens)
             wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
             e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
             e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
-            linear(s, WA_EPI_DEC_QKV, st.d_dxn, d, L.qkv, n_tokens, e);
+            linear(s, ctx.exact, WA_EPI_DEC_QKV, st.d_dxn, d, L.qkv, n_tokens, e);
         }
-        wa_launch_dec_self_attn(s, st.d_dq, d, kv.k + il * kv_layer, kv.v + il * kv_layer, d, H, n_tokens, n_kv, mask, st.d_scores,
-                                st.d_dao, d);
+        wa_launch_attn_exact(s, st.d_dq, d, kv.k + il * kv_layer, 64, d, kv.v + il * kv_layer, 64, d, H, n_tokens, n_kv, mask, 1.0f,
+                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr);
         {
             wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
-            linear(s, WA_EPI_RESID, st.d_dao, d, L.out, n_tokens, e);
+            linear(s, ctx.exact, WA_EPI_RESID, st.d_dao, d, L.out, n_tokens, e);
         }
         // ---- cross-attention over the encoder K/V ----
-        wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, L.cross_ln.w, L.cross_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.cross_ln.w, L.cross_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
         {
             wa_epi e; e.bias = L.cross_q.b; e.out = st.d_dq; e.ldo = d;
-            linear(s, WA_EPI_F16, st.d_dxn, d, L.cross_q, n_tokens, e);
+            linear(s, ctx.exact, WA_EPI_F16, st.d_dxn, d, L.cross_q, n_tokens, e);
         }
         float * qk_out = nullptr;
         if (save_aheads && st.d_aheads_qk && il < (int) st.aheads.size() && !st.aheads[il].empty())
             qk_out = st.d_aheads_qk + (size_t) il * n_tokens * H * T;
-        wa_launch_dec_cross_attn(s, st.d_dq, d, st.d_cross_k + il * cross_layer, st.d_cross_v + il * cross_layer, st.cross_tpad, T, H,
-                                 n_tokens, KQscale, st.d_scores, st.d_dao, d, qk_out);
+        wa_launch_attn_exact(s, st.d_dq, d, st.d_cross_k + il * cross_layer, (size_t) st.cross_tpad * 64, 64, st.d_cross_v + il * cross_layer,
+                             (size_t) st.cross_tpad * 64, 64, H, n_tokens, T, nullptr, KQscale, st.d_att_partial, st.d_att_pleft, st.d_dao, d, qk_out);
         {
             wa_epi e; e.bias = L.cross_out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
-            linear(s, WA_EPI_RESID, st.d_dao, d, L.cross_out, n_tokens, e);
+            linear(s, ctx.exact, WA_EPI_RESID, st.d_dao, d, L.cross_out, n_tokens, e);
         }
         // ---- feed-forward ----
-        wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
         {
             wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_dff; e.ldo = 4 * d;
-            linear(s, WA_EPI_GELU_F16, st.d_dxn, d, L.fc1, n_tokens, e);
+            linear(s, ctx.exact, WA_EPI_GELU_F16, st.d_dxn, d, L.fc1, n_tokens, e);
         }
         {
             wa_epi e; e.bias = L.fc2.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
-            linear(s, WA_EPI_RESID, st.d_dff, 4 * d, L.fc2, n_tokens, e);
+            linear(s, ctx.exact, WA_EPI_RESID, st.d_dff, 4 * d, L.fc2, n_tokens, e);
         }
     }
-    wa_launch_layernorm(s, st.d_dx, d, n_tokens, d, m.d_ln.w, m.d_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
+    wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, m.d_ln.w, m.d_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
 
     // logits = token_embedding . x for the flagged rows only (the reference computes all rows and
     // copies out the flagged ones, whisper.cpp:2835, 2965-2971)
     if (n_rows) {
-        wa_launch_logits(s, st.d_dxn, d, st.d_rows, n_rows, m.d_te, d, n_vocab, d, st.d_logits);
+        wa_epi e; e.out = st.d_logits; e.ldo = n_vocab;
+        wa_launch_gemv_exact(s, WA_EPI_F32, st.d_dxn, d, st.d_rows, m.d_te, d, n_rows, n_vocab, d, e);
     }
 }
 

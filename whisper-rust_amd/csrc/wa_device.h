@@ -1,0 +1,149 @@
+// wa_device.h - device-side helpers shared by wa_kernels.hip (MFMA "flash" path) and wa_exact.hip
+// (reference-order path): F16 conversion, wave reductions, ggml's expf polynomial, the GELU table
+// lookup and the GEMM epilogues.
+#pragma once
+#include "wa_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 h16;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+__device__ __forceinline__ float h2f(wa_f16 v) { union { wa_f16 u; h16 h; } c; c.u = v; return (float) c.h; }
+__device__ __forceinline__ wa_f16 f2h(float v) { union { wa_f16 u; h16 h; } c; c.h = (h16) v; return c.u; }   // RNE
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// ggml's vectorised expf (vec.h:774-811, the AVX2+FMA flavour the reference CPU path runs for all
+// but the last n%8 softmax elements), restated in scalar form with the same operation order.
+__device__ __forceinline__ float wa_expf(float x) {
+    const float r = 0x1.8p23f;
+    const float z = fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    const float b = fmaf(-n, 0x1.7f7d1cp-20f, fmaf(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = __float_as_uint(z) << 23;
+    const float k = __uint_as_float(e + __float_as_uint(1.0f));
+    const float an = fabsf(n);
+    const float u = b * b;
+    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u,
+                         0x1.ffffecp-1f * b);
+    if (!(an > 126.0f)) return fmaf(j, k, k);
+    const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float s1 = __uint_as_float(g + 0x7f000000u);
+    const float s2 = __uint_as_float(e - g);
+    if (an > 192.0f) return s1 * s1;
+    return fmaf(s2, j, s2) * s1;
+}
+
+// GELU exactly as ggml_vec_gelu_f32 with GGML_GELU_FP16 (vec.h:571-585): table lookup on the F16
+// bits of x, identity above 10, zero below -10.  Result is an F32 that is exactly F16-representable
+// (or x itself for x >= 10).
+__device__ __forceinline__ float wa_gelu(float x, const wa_f16 * __restrict__ table) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >=  10.0f) return x;
+    return h2f(table[f2h(x)]);
+}
+
+// =================================================================================================
+// GEMM epilogues (shared by the MFMA GEMM and the GEMV)
+// =================================================================================================
+template <int EPI>
+__device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float acc) {
+    float v = acc;
+    if (EPI != WA_EPI_F32 || e.bias) { if (e.bias) v = v + e.bias[n]; }
+    if (EPI == WA_EPI_F16) {
+        if (e.scale) v = v * e.scale[n];
+        ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
+    } else if (EPI == WA_EPI_ENC_QKV) {
+        if (n < e.split0) ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
+        else              ((wa_f16 *) e.out2)[(size_t) (n - e.split0) * e.ldo2 + m] = f2h(v);
+    } else if (EPI == WA_EPI_GELU_F16) {
+        ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(wa_gelu(v, e.gelu));
+    } else if (EPI == WA_EPI_RESID) {
+        ((float *) e.out)[(size_t) m * e.ldo + n] = v + e.resid[(size_t) m * e.ldr + n];
+    } else if (EPI == WA_EPI_CONV2) {
+        const float g = wa_gelu(v, e.gelu);
+        if (e.dbg) e.dbg[(size_t) m * e.ldo + n] = g;
+        ((float *) e.out)[(size_t) m * e.ldo + n] = e.resid[(size_t) m * e.ldr + n] + g;
+    } else if (EPI == WA_EPI_F32) {
+        ((float *) e.out)[(size_t) m * e.ldo + n] = v;
+    } else if (EPI == WA_EPI_CROSS_KV) {
+        // n = layer*2d + kv*d + head*64 + c ; aux0 = tpad, aux1 = d
+        if (e.scale) v = v * e.scale[n];
+        const int d = e.aux1, two_d = 2 * d;
+        const int il = n / two_d, r = n - il * two_d;
+        const int kv = r >= d, rr = kv ? r - d : r;
+        const int n_head = d >> 6, hd = rr >> 6, c = rr & 63;
+        wa_f16 * dst = (wa_f16 *) (kv ? e.out2 : e.out);
+        dst[(((size_t) il * n_head + hd) * e.aux0 + m) * 64 + c] = f2h(v);
+    } else if (EPI == WA_EPI_DEC_QKV) {
+        if (e.scale) v = v * e.scale[n];
+        if (n < e.split0)      ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
+        else if (n < e.split1) ((wa_f16 *) e.out2)[(size_t) (e.row_off + m) * e.ldo2 + (n - e.split0)] = f2h(v);
+        else                   ((wa_f16 *) e.out3)[(size_t) (e.row_off + m) * e.ldo3 + (n - e.split1)] = f2h(v);
+    }
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// reference-order helpers (wa_exact.hip)
+// -------------------------------------------------------------------------------------------------
+// Final reduction of ggml_vec_dot_f16's 4x8 partial sums (simd-mappings.h:367-385): s[j*8 + l]
+__device__ __forceinline__ float wa_tree32(const float (&s)[32]) {
+    float a[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) a[l] = (s[l] + s[16 + l]) + (s[8 + l] + s[24 + l]);
+    const float t0 = a[0] + a[4], t1 = a[1] + a[5], t2 = a[2] + a[6], t3 = a[3] + a[7];
+    return (t0 + t1) + (t2 + t3);
+}
+
+// glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, FMA ifunc variant) restated in F64: the reference's
+// softmax calls libm expf for the last n%8 elements of every row (vec.cpp:301-305).  Validated on the
+// build host against libm: 1 mismatch (1 ulp) in 4e7 arguments of [-110, 0].
+static __device__ const unsigned long long WA_EXP2F_T[32] = {
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, 0x3fef72b83c7d517bULL,
+    0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, 0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL,
+    0x3feedea64c123422ULL, 0x3feece086061892dULL, 0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL,
+    0x3feea47eb03a5585ULL, 0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, 0x3feee89f995ad3adULL,
+    0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL,
+    0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL,
+};
+__device__ __forceinline__ float wa_expf_libm(float x) {
+    if (!(x >= -0x1.9fe368p6f)) return 0.0f;            // underflow and -inf (arguments here are always <= 0)
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double SHIFT = 0x1.8p+52;
+    double z = InvLn2N * (double) x;
+    double kd = z + SHIFT;
+    const unsigned long long ki = (unsigned long long) __double_as_longlong(kd);
+    kd = kd - SHIFT;
+    const double r = z - kd;
+    const unsigned long long t = WA_EXP2F_T[ki & 31] + (ki << 47);
+    const double s = __longlong_as_double((long long) t);
+    z = fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = fma(C2, r, 1.0);
+    y = fma(z, r2, y);
+    y = y * s;
+    return (float) y;
+}

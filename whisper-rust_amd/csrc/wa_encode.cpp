@@ -29,10 +29,6 @@ bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells) 
     st.kv_self.cells.assign(n_cells, wa_kv_cell());
     const size_t n = (size_t) hp.n_text_layer * n_cells * hp.n_text_state;
     if (!dev_alloc(st.kv_self.k, n) || !dev_alloc(st.kv_self.v, n)) return false;
-    // score scratch must cover max(n_audio_ctx, kv cells) per (token, head)
-    dev_free(st.d_scores);
-    const int ld = std::max(hp.n_audio_ctx, n_cells);
-    if (!dev_alloc(st.d_scores, (size_t) st.dec_mpad * hp.n_text_head * ld, false)) return false;
     dev_free(st.d_mask);
     st.d_mask_cap = (size_t) st.dec_mpad * n_cells;
     if (!dev_alloc(st.d_mask, st.d_mask_cap)) return false;
@@ -79,6 +75,8 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
     if (!dev_alloc(st.d_dff,  (size_t) mpad * 4 * d)) return false;
     if (!dev_alloc(st.d_dq,   (size_t) mpad * d)) return false;
     if (!dev_alloc(st.d_logits, (size_t) WA_MAX_DECODERS * hp.n_vocab, false)) return false;
+    if (!dev_alloc(st.d_att_partial, (size_t) 512 * 32 * 64) || !dev_alloc(st.d_att_pleft, (size_t) 512 * 32)) return false;
+    if (!dev_alloc(st.d_im2col, std::max((size_t) 2 * T * 3 * hp.n_mels, (size_t) T * 3 * d) + 64)) return false;
     if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_stage_i32, (size_t) 4 * mpad * sizeof(int32_t)))) return false;
     st.h_logits_cap = (size_t) WA_MAX_DECODERS * hp.n_vocab;
     if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_logits_pinned, st.h_logits_cap * sizeof(float)))) return false;
@@ -103,7 +101,7 @@ void wa_state_release(whisper_state & st) {
     dev_free(st.kv_self.k); dev_free(st.kv_self.v);
     dev_free(st.d_tok); dev_free(st.d_pos); dev_free(st.d_cell); dev_free(st.d_rows); dev_free(st.d_mask);
     dev_free(st.d_dx); dev_free(st.d_dxn); dev_free(st.d_dqkv); dev_free(st.d_dao); dev_free(st.d_dff); dev_free(st.d_dq);
-    dev_free(st.d_scores); dev_free(st.d_logits); dev_free(st.d_aheads_qk);
+    dev_free(st.d_att_partial); dev_free(st.d_att_pleft); dev_free(st.d_im2col); dev_free(st.d_logits); dev_free(st.d_aheads_qk);
     if (st.h_stage_i32)     { (void) hipHostFree(st.h_stage_i32);     st.h_stage_i32 = nullptr; }
     if (st.h_stage_mask)    { (void) hipHostFree(st.h_stage_mask);    st.h_stage_mask = nullptr; }
     if (st.h_logits_pinned) { (void) hipHostFree(st.h_logits_pinned); st.h_logits_pinned = nullptr; }
@@ -195,49 +193,72 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
     const int rows_total = 2 * T + 8;
     wa_launch_mel_window(s, st.d_mel, hp.n_mels, st.mel_n_len, mel_offset, 2 * T, st.d_melT, rows_total);
 
-    // conv1 (k3 s1 p1) + bias + GELU: out row t reads melT rows t..t+2 == one contiguous K = 3*n_mels run
+    // Two interchangeable implementations of every dense product:
+    //   exact (flash_attn == false): reference summation order on the VALU -> bit-identical to whisper.cpp CPU
+    //   fast  (flash_attn == true) : MFMA (v_mfma_f32_16x16x32_f16), same rounding points, different F32 order
+    const bool exact = ctx.exact;
+    auto gemm = [&](wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
+        if (exact) wa_launch_gemm_exact(s, mode, A, lda, W, ldw, M, N, K, e);
+        else       wa_launch_gemm(s, mode, A, lda, W, ldw, M, N, K, e);
+    };
+
+    // conv1 (k3 s1 p1) + bias + GELU -> h1 (F16, time-major, one zero row in front = conv2's left padding)
     {
-        wa_epi e; e.bias = m.conv1.b; e.gelu = m.d_gelu; e.out = st.d_h1 + d; e.ldo = d;   // row 0 of h1 stays zero
-        wa_launch_gemm(s, WA_EPI_GELU_F16, st.d_melT, hp.n_mels, m.conv1.w, m.conv1_kpad, 2 * T, d, m.conv1_kpad, e);
+        wa_epi e; e.bias = m.conv1.b; e.gelu = m.d_gelu; e.out = st.d_h1 + d; e.ldo = d;
+        if (exact) {   // im2col in ggml's column order ic*3+k (ops.cpp:5925-5937), K = 3*n_mels with F64 leftovers
+            wa_launch_im2col3(s, st.d_melT, hp.n_mels, 0, 1, hp.n_mels, 2 * T, st.d_im2col, 3 * hp.n_mels);
+            wa_launch_gemm_exact(s, WA_EPI_GELU_F16, st.d_im2col, 3 * hp.n_mels, m.conv1_g, 3 * hp.n_mels, 2 * T, d, 3 * hp.n_mels, e);
+        } else {       // out row t reads melT rows t..t+2 == one contiguous run of the k-major weights: no im2col buffer
+            wa_launch_gemm(s, WA_EPI_GELU_F16, st.d_melT, hp.n_mels, m.conv1.w, m.conv1_kpad, 2 * T, d, m.conv1_kpad, e);
+        }
     }
-    // rows of h1 beyond 2T must read as zero for conv2's right padding: they are never written.
-    // conv2 (k3 s2 p1) + bias + GELU, then + positional embedding: out row t reads h1 rows 2t..2t+2 (with the +1 shift)
+    // conv2 (k3 s2 p1) + bias + GELU, then + positional embedding -> residual stream x (F32)
     {
         wa_epi e; e.bias = m.conv2.b; e.gelu = m.d_gelu; e.out = st.d_x; e.ldo = d; e.resid = m.e_pe; e.ldr = d; e.dbg = st.d_embd_conv;
-        wa_launch_gemm(s, WA_EPI_CONV2, st.d_h1, 2 * d, m.conv2.w, 3 * d, T, d, 3 * d, e);
+        if (exact) {
+            wa_launch_im2col3(s, st.d_h1, d, 0, 2, d, T, st.d_im2col, 3 * d);
+            wa_launch_gemm_exact(s, WA_EPI_CONV2, st.d_im2col, 3 * d, m.conv2_g, 3 * d, T, d, 3 * d, e);
+        } else {       // out row t reads h1 rows 2t..2t+2 (with the +1 row shift) as a strided view
+            wa_launch_gemm(s, WA_EPI_CONV2, st.d_h1, 2 * d, m.conv2.w, 3 * d, T, d, 3 * d, e);
+        }
     }
 
     const float KQscale = 1.0f / sqrtf(float(64));    // whisper.cpp:2087
     for (int il = 0; il < hp.n_audio_layer; ++il) {
         const auto & L = m.enc[il];
-        wa_launch_layernorm(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
-        {   // fused Q | K | V projection; V lands transposed for the P V product
+        wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        if (exact) {   // Q | K | V row-major in one [T][3d] buffer (the FFN buffer is free here)
+            wa_epi e; e.bias = L.qkv.b; e.out = st.d_ff; e.ldo = 3 * d;
+            wa_launch_gemm_exact(s, WA_EPI_F16, st.d_xn, d, L.qkv.w, d, T, 3 * d, d, e);
+            wa_launch_attn_exact(s, st.d_ff, 3 * d, st.d_ff + d, 64, 3 * d, st.d_ff + 2 * d, 64, 3 * d, H, T, T, nullptr, KQscale,
+                                 st.d_att_partial, st.d_att_pleft, st.d_ao, d, nullptr);
+        } else {       // V lands transposed for the MFMA P V product
             wa_epi e; e.bias = L.qkv.b; e.out = st.d_qk; e.ldo = 2 * d; e.out2 = st.d_vt; e.ldo2 = tpad; e.split0 = 2 * d;
             wa_launch_gemm(s, WA_EPI_ENC_QKV, st.d_xn, d, L.qkv.w, d, T, 3 * d, d, e);
+            wa_launch_enc_attn(s, st.d_qk, 2 * d, st.d_vt, tpad, T, d, H, KQscale, st.d_ao, d);
         }
-        wa_launch_enc_attn(s, st.d_qk, 2 * d, st.d_vt, tpad, T, d, H, KQscale, st.d_ao, d);
         {   // out projection + bias + residual
             wa_epi e; e.bias = L.out.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d;
-            wa_launch_gemm(s, WA_EPI_RESID, st.d_ao, d, L.out.w, d, T, d, d, e);
+            gemm(WA_EPI_RESID, st.d_ao, d, L.out.w, d, T, d, d, e);
         }
-        wa_launch_layernorm(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
         {
             wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_ff; e.ldo = 4 * d;
-            wa_launch_gemm(s, WA_EPI_GELU_F16, st.d_xn, d, L.fc1.w, d, T, 4 * d, d, e);
+            gemm(WA_EPI_GELU_F16, st.d_xn, d, L.fc1.w, d, T, 4 * d, d, e);
         }
         {
             wa_epi e; e.bias = L.fc2.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d;
-            wa_launch_gemm(s, WA_EPI_RESID, st.d_ff, 4 * d, L.fc2.w, 4 * d, T, d, 4 * d, e);
+            gemm(WA_EPI_RESID, st.d_ff, 4 * d, L.fc2.w, 4 * d, T, d, 4 * d, e);
         }
     }
     // ln_post -> F32 encoder output (API / tests) + F16 copy (operand of the cross K/V GEMM)
-    wa_launch_layernorm(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, st.d_xn, d, st.d_embd_enc, d);
+    wa_launch_layernorm_exact(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, st.d_xn, d, st.d_embd_enc, d);
 
     // cross-attention K/V of ALL decoder layers in one GEMM (whisper.cpp:2290-2364):
     // K = (Wk enc) * d_h^-1/4, V = Wv enc + b, both F16, laid out [layer][head][t][64]
     {
         wa_epi e; e.bias = m.cross_kv.b; e.scale = m.cross_kv.s; e.out = st.d_cross_k; e.out2 = st.d_cross_v; e.aux0 = st.cross_tpad; e.aux1 = d;
-        wa_launch_gemm(s, WA_EPI_CROSS_KV, st.d_xn, d, m.cross_kv.w, d, T, hp.n_text_layer * 2 * d, d, e);
+        gemm(WA_EPI_CROSS_KV, st.d_xn, d, m.cross_kv.w, d, T, hp.n_text_layer * 2 * d, d, e);
     }
     if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
     st.have_enc = true;

@@ -1,0 +1,429 @@
+// wa_exact.hip - the REFERENCE-ORDER kernels: every floating-point sum is formed in exactly the order
+// the reference's ggml-cpu AVX2 path forms it, so results are bit-identical to whisper.cpp CPU
+// (oracle/whisper_oracle.cpp is the scalar statement of the same order, pinned bit-exact to the
+// reference engine).  Used for (a) every decode-step kernel - the decode step is HBM-bound, the order costs
+// nothing - and (b) the encoder / prompt GEMMs and attention when flash_attn == false.
+//
+//   dot products   ggml_vec_dot_f16 (vec.cpp:191-231): 32 F32 partial sums s[i mod 32], each an FMA
+//                  chain in k order; fixed reduction tree (wa_tree32); K % 32 leftovers added in F64.
+//   soft_max       ops.cpp:4792-4818 + vec.cpp:257-308: expf polynomial on groups of 8 with the 8-lane
+//                  tree, F64 running sum in group order, libm expf for the n % 8 tail.
+//   norm           ops.cpp:3225-3242: F64 sums; evaluated in parallel when an exponent-range certificate
+//                  proves every partial sum exact (then any order gives the reference's value), else by
+//                  one lane in index order.
+// Compiled with -ffp-contract=off: fmaf is the only fused operation.
+#include "wa_device.h"
+
+// =================================================================================================
+// GEMM (any M): C = A W^T in ggml_vec_dot_f16 order.  VALU, not MFMA: the MFMA's internal summation
+// order is not the reference's.  Block = 4 waves in 2x2; wave = 8x8 lanes, each lane owns a 2x2 output
+// patch with all 32 partial sums of each output in registers (128 accumulators), so the final tree is
+// lane-local.  LDS rows are 40 halfs: the b128 reads of a 16-lane group hit disjoint banks.
+// Roofline: F32 VALU-bound (157 TFLOP/s peak), 128 FMAs per 16 LDS b128 reads.
+// =================================================================================================
+#define EX_LD 40
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_exact(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
+                                                       int M, int N, int K, wa_epi e) {
+    __shared__ __attribute__((aligned(16))) wa_f16 As[2][32 * EX_LD];
+    __shared__ __attribute__((aligned(16))) wa_f16 Ws[2][32 * EX_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane >> 3, lj = lane & 7;
+    const int tiles_n = (N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+
+    float acc[2][2][32];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[p][q][i] = 0.0f;
+
+    const int np = K & ~31, nsteps = np >> 5;
+    // global -> LDS staging: threads 0..127 carry A chunks, 128..255 carry W chunks (16 B each)
+    const int lrow = (tid & 127) >> 2, lkc = tid & 3;
+    const bool isA = tid < 128;
+    const wa_f16 * gsrc;
+    {
+        if (isA) { int gm = m0 + lrow; gm = gm < M ? gm : M - 1; gsrc = A + (size_t) gm * lda + lkc * 8; }
+        else     { int gn = n0 + lrow; gn = gn < N ? gn : N - 1; gsrc = W + (size_t) gn * ldw + lkc * 8; }
+    }
+    uint4 stage = make_uint4(0, 0, 0, 0);
+    if (nsteps > 0) stage = *(const uint4 *) gsrc;
+    if (nsteps > 0) {
+        *(uint4 *) (isA ? &As[0][lrow * EX_LD + lkc * 8] : &Ws[0][lrow * EX_LD + lkc * 8]) = stage;
+    }
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) stage = *(const uint4 *) (gsrc + (s + 1) * 32);
+        half8 a[2][4], w[2][4];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[p][c] = *(const half8 *) (&As[buf][(wm * 16 + li * 2 + p) * EX_LD + c * 8]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[q][c] = *(const half8 *) (&Ws[buf][(wn * 16 + lj * 2 + q) * EX_LD + c * 8]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        acc[p][q][c * 8 + i] = fmaf((float) w[q][c][i], (float) a[p][c][i], acc[p][q][c * 8 + i]);
+        if (s + 1 < nsteps) *(uint4 *) (isA ? &As[buf ^ 1][lrow * EX_LD + lkc * 8] : &Ws[buf ^ 1][lrow * EX_LD + lkc * 8]) = stage;
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = m0 + wm * 16 + li * 2 + p, n = n0 + wn * 16 + lj * 2 + q;
+            if (m < M && n < N) {
+                float res = wa_tree32(acc[p][q]);
+                if (np < K) {      // leftovers in F64, index order (vec.cpp:221-223)
+                    double sumf = (double) res;
+                    const wa_f16 * ar = A + (size_t) m * lda, * wr = W + (size_t) n * ldw;
+                    for (int i = np; i < K; ++i) sumf += (double) (h2f(wr[i]) * h2f(ar[i]));
+                    res = (float) sumf;
+                }
+                epi_store<EPI>(e, m, n, res);
+            }
+        }
+}
+
+void wa_launch_gemm_exact(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
+                          const wa_epi & e) {
+    const int grid = ((M + 31) / 32) * ((N + 31) / 32);
+#define WA_CASE(E) case E: hipLaunchKernelGGL((k_gemm_exact<E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); break;
+    switch (mode) {
+        WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_ENC_QKV) WA_CASE(WA_EPI_GELU_F16) WA_CASE(WA_EPI_RESID)
+        WA_CASE(WA_EPI_CONV2) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_CROSS_KV) WA_CASE(WA_EPI_DEC_QKV)
+    }
+#undef WA_CASE
+}
+
+// =================================================================================================
+// GEMV (M <= 8 tokens, K % 32 == 0): weight streaming, HBM-bound.  8 lanes per output row: lane u owns
+// elements 4u..4u+3 of every 32-element block, i.e. partial sums (j = u/2, l = 4(u%2)+e); the xor-4 / xor-2 /
+// xor-1 exchanges then reproduce the reference's (s0+s2)+(s1+s3), l<->l+4 and final pairings exactly.
+// Activations staged once per block in LDS; weights go straight from HBM to VGPRs (8 B per lane per step).
+// =================================================================================================
+template <int MT, int EPI>
+__global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ A, int lda, const int32_t * __restrict__ rows,
+                                                    const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
+    extern __shared__ __attribute__((aligned(16))) wa_f16 xs[];   // [MT][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kc = K >> 3;
+    for (int c = tid; c < MT * kc; c += 128) {
+        const int m = c / kc, cc = c - m * kc;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < M) { const int src = rows ? rows[m] : m; v = *(const uint4 *) (A + (size_t) src * lda + cc * 8); }
+        *(uint4 *) (&xs[(size_t) m * K + cc * 8]) = v;
+    }
+    __syncthreads();
+    const int u = lane & 7, slot = lane >> 3;
+    const int nsteps = K >> 5;
+    for (int nb = blockIdx.x * 16; nb < N; nb += gridDim.x * 16) {
+        const int n = nb + wave * 8 + slot;
+        const int nn = n < N ? n : N - 1;
+        const wa_f16 * wrow = W + (size_t) nn * ldw + 4 * u;
+        float acc[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m][i] = 0.0f;
+#pragma unroll 4
+        for (int s = 0; s < nsteps; ++s) {
+            const uint2 wv = *(const uint2 *) (wrow + s * 32);
+            const wa_f16 * w4 = (const wa_f16 *) &wv;
+            const float w0 = h2f(w4[0]), w1 = h2f(w4[1]), w2 = h2f(w4[2]), w3 = h2f(w4[3]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const uint2 xv = *(const uint2 *) (&xs[(size_t) m * K + s * 32 + 4 * u]);
+                const wa_f16 * x4 = (const wa_f16 *) &xv;
+                acc[m][0] = fmaf(w0, h2f(x4[0]), acc[m][0]);
+                acc[m][1] = fmaf(w1, h2f(x4[1]), acc[m][1]);
+                acc[m][2] = fmaf(w2, h2f(x4[2]), acc[m][2]);
+                acc[m][3] = fmaf(w3, h2f(x4[3]), acc[m][3]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[m][i];
+                v = v + __shfl_xor(v, 4, WAVE);     // s[j] + s[j+2]
+                v = v + __shfl_xor(v, 2, WAVE);     // (s0+s2) + (s1+s3)
+                t[i] = v + __shfl_xor(v, 1, WAVE);  // a[l] + a[l+4]
+            }
+            const float res = (t[0] + t[1]) + (t[2] + t[3]);
+            if (u == 0 && n < N && m < M) epi_store<EPI>(e, m, n, res);
+        }
+    }
+}
+
+template <int MT>
+static void gemv_exact_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
+                                int M, int N, int K, const wa_epi & e) {
+    int grid = (N + 15) / 16;
+    if (grid > 4096) grid = 4096;
+    const size_t lds = (size_t) MT * K * sizeof(wa_f16);
+#define WA_CASE(E) case E: { \
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_gemv_exact<MT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+        hipLaunchKernelGGL((k_gemv_exact<MT, E>), dim3(grid), dim3(128), lds, s, A, lda, rows, W, ldw, M, N, K, e); } break;
+    switch (mode) {
+        WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_GELU_F16) WA_CASE(WA_EPI_RESID) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_DEC_QKV)
+        default: break;
+    }
+#undef WA_CASE
+}
+
+void wa_launch_gemv_exact(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
+                          int M, int N, int K, const wa_epi & e) {
+    if (M <= 1)      gemv_exact_dispatch<1>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+    else if (M <= 2) gemv_exact_dispatch<2>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+    else if (M <= 4) gemv_exact_dispatch<4>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+    else             gemv_exact_dispatch<8>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+}
+
+// =================================================================================================
+// im2col in ggml's column order (ops.cpp:5925-5937): dst[t][ic*3 + k] = src[(t*stride + k + row0)][ic]
+// src is time-major F16 with the conv's zero padding already materialised as zero rows.
+// =================================================================================================
+__global__ void k_im2col3(const wa_f16 * __restrict__ src, int src_ld, int row0, int stride, int IC, int OL, wa_f16 * __restrict__ dst, int dst_ld) {
+    const size_t total = (size_t) OL * IC * 3;
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < total; i += (size_t) gridDim.x * blockDim.x) {
+        const int t = (int) (i / (IC * 3)), r = (int) (i - (size_t) t * IC * 3);
+        const int ic = r / 3, k = r - ic * 3;
+        dst[(size_t) t * dst_ld + r] = src[(size_t) (t * stride + k + row0) * src_ld + ic];
+    }
+}
+void wa_launch_im2col3(hipStream_t s, const wa_f16 * src, int src_ld, int row0, int stride, int IC, int OL, wa_f16 * dst, int dst_ld) {
+    const size_t total = (size_t) OL * IC * 3;
+    int grid = (int) ((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_im2col3, dim3(grid), dim3(256), 0, s, src, src_ld, row0, stride, IC, OL, dst, dst_ld);
+}
+
+// =================================================================================================
+// LayerNorm in reference order (ops.cpp:3225-3242): one wave per row.
+// =================================================================================================
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, WAVE); v = v > t ? v : t; }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, WAVE); v = v < t ? v : t; }
+    return v;
+}
+// biased exponent of a non-zero float; denormals report -1000 so that the certificate fails
+__device__ __forceinline__ int f32_exp(float x) { const int e = (__float_as_uint(x) >> 23) & 0xff; return e == 0 ? -1000 : e; }
+
+__global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
+                                                         const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
+                                                         float * __restrict__ out32, int ld32) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float * xr = x + (size_t) row * ldx;
+    // Every partial sum of addends whose exponents span <= 18 binades (d <= 2048) is exact in F64, so the
+    // parallel sum equals the reference's index-order sum; otherwise one lane walks the row in order.
+    double s = 0.0;
+    int emax = -2000, emin = 2000;
+    for (int i = lane; i < d; i += 64) {
+        const float v = xr[i];
+        s += (double) v;
+        if (v != 0.0f) { const int e = f32_exp(v); emax = e > emax ? e : emax; emin = e < emin ? e : emin; }
+    }
+    s = wave_sum_d(s);
+    emax = wave_max_i(emax); emin = wave_min_i(emin);
+    if (emax - emin > 18) {
+        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) t += (double) xr[i]; s = t; }
+        s = __shfl(s, 0, WAVE);
+    }
+    const float mean = (float) (s / (double) d);
+    double s2 = 0.0;
+    emax = -2000; emin = 2000;
+    for (int i = lane; i < d; i += 64) {
+        const float v = xr[i] - mean;
+        const float vv = v * v;
+        s2 += (double) vv;
+        if (vv != 0.0f) { const int e = f32_exp(vv); emax = e > emax ? e : emax; emin = e < emin ? e : emin; }
+    }
+    s2 = wave_sum_d(s2);
+    emax = wave_max_i(emax); emin = wave_min_i(emin);
+    if (emax - emin > 18) {
+        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) { const float v = xr[i] - mean; t += (double) (v * v); } s2 = t; }
+        s2 = __shfl(s2, 0, WAVE);
+    }
+    const float variance = (float) (s2 / (double) d);
+    const float scale = 1.0f / sqrtf(variance + eps);
+    for (int i = lane; i < d; i += 64) {
+        float y = xr[i] - mean;
+        y = y * scale;
+        y = y * w[i];
+        y = y + b[i];
+        if (out16) out16[(size_t) row * ld16 + i] = f2h(y);
+        if (out32) out32[(size_t) row * ld32 + i] = y;
+    }
+}
+void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
+                               wa_f16 * out16, int ld16, float * out32, int ld32) {
+    hipLaunchKernelGGL(k_layernorm_exact, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32);
+}
+
+// =================================================================================================
+// Attention in reference order, d_head = 64, one (query, head) per block (x RS residue splits):
+//   scores  s[c] = vec_dot_f16(64; K[c], q) -> * scale (+ mask)                 (whisper.cpp:2636 / 2189 / 2732)
+//   softmax exactly as ops.cpp:4792-4818                                        (F32 probabilities)
+//   out[dh] = vec_dot_f16(n_kv; V[.][dh], f16(P))                               (whisper.cpp:2647 / 2202 / 2754)
+// The 32 partial-sum chains of the P V product (cells c = r mod 32) are independent: RS == 1 keeps all of
+// them in the block and finishes in LDS (encoder: thousands of blocks); RS == 4 spreads them over 4 blocks
+// per (query, head) to put more CUs on a single decode token and leaves the tree to k_attn_combine.
+// =================================================================================================
+#define ATT_MAXKV 4096
+
+template <int RS>
+__global__ __launch_bounds__(256) void k_attn_exact(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
+                                                    int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
+                                                    int n_kv, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
+                                                    wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out) {
+    __shared__ float sc[ATT_MAXKV];
+    __shared__ wa_f16 p16[ATT_MAXKV];
+    __shared__ float gs[ATT_MAXKV / 8];
+    __shared__ float red[4];
+    __shared__ float s_inv;
+    __shared__ __attribute__((aligned(16))) wa_f16 qs[64];
+    __shared__ float part[RS == 1 ? 32 * 64 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_head = gridDim.x / RS;
+    const int h = blockIdx.x / RS, rs = blockIdx.x % RS, j = blockIdx.y;
+    const wa_f16 * kp = kbase + (size_t) h * k_head_stride;
+    const wa_f16 * vp = vbase + (size_t) h * v_head_stride;
+    const int8_t * mrow = mask ? mask + (size_t) j * n_kv : nullptr;
+
+    if (tid < 64) qs[tid] = q[(size_t) j * ldq + h * 64 + tid];
+    __syncthreads();
+
+    // ---- scores ----
+    float lmax = -INFINITY;
+    for (int c = tid; c < n_kv; c += 256) {
+        const wa_f16 * kr = kp + (size_t) c * k_row_stride;
+        uint4 kv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kv[i] = *(const uint4 *) (kr + i * 8);
+        const wa_f16 * k64 = (const wa_f16 *) kv;
+        float s[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s[i] = fmaf(h2f(k64[i]), h2f(qs[i]), 0.0f);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s[i] = fmaf(h2f(k64[32 + i]), h2f(qs[32 + i]), s[i]);
+        float a = wa_tree32(s) * scale;
+        if (mrow && mrow[c]) a = -INFINITY;
+        sc[c] = a;
+        lmax = fmaxf(lmax, a);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+
+    // ---- exp: polynomial for the multiple-of-8 body, libm expf for the tail ----
+    const int n8 = n_kv & ~7;
+    for (int c = tid; c < n_kv; c += 256) sc[c] = c < n8 ? wa_expf(sc[c] - mx) : wa_expf_libm(sc[c] - mx);
+    __syncthreads();
+    for (int g = tid; g < (n8 >> 3); g += 256) {
+        const float * v = &sc[g * 8];
+        gs[g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+    }
+    __syncthreads();
+    if (tid == 0) {                       // F64 running sum in group order (vec.cpp:278-305)
+        double sum = 0.0;
+        for (int g = 0; g < (n8 >> 3); ++g) sum += (double) gs[g];
+        for (int c = n8; c < n_kv; ++c) sum += (double) sc[c];
+        s_inv = (float) (1.0 / sum);
+    }
+    __syncthreads();
+    const float inv = s_inv;
+    for (int c = tid; c < n_kv; c += 256) {
+        const float p = sc[c] * inv;
+        if (qk_out && rs == 0) qk_out[((size_t) j * n_head + h) * n_kv + c] = p;
+        p16[c] = f2h(p);
+    }
+    __syncthreads();
+
+    // ---- P V: chains r = c mod 32, lane = dh ----
+    const int np = n_kv & ~31, nsteps = np >> 5;
+    constexpr int RPW = 32 / RS / 4;      // residues per wave
+    float acc[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) acc[i] = 0.0f;
+    const int r0 = rs * (32 / RS) + wave * RPW;
+    for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int c = s * 32 + r0 + i;
+            acc[i] = fmaf(h2f(vp[(size_t) c * v_row_stride + lane]), h2f(p16[c]), acc[i]);
+        }
+    }
+    if (RS == 1) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) part[(r0 + i) * 64 + lane] = acc[i];
+        __syncthreads();
+        if (tid < 64) {
+            float s32[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
+            double sumf = (double) wa_tree32(s32);
+            for (int c = np; c < n_kv; ++c) sumf += (double) (h2f(vp[(size_t) c * v_row_stride + tid]) * h2f(p16[c]));
+            out[(size_t) j * ldo + h * 64 + tid] = f2h((float) sumf);
+        }
+    } else {
+        const size_t pb = ((size_t) j * n_head + h) * 32;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) partial[(pb + r0 + i) * 64 + lane] = acc[i];
+        if (rs == 0 && tid < 32) p_left[pb + tid] = (np + tid < n_kv) ? p16[np + tid] : (wa_f16) 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ partial, const wa_f16 * __restrict__ p_left,
+                                                     const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride, int n_kv,
+                                                     wa_f16 * __restrict__ out, int ldo) {
+    const int j = blockIdx.x, h = blockIdx.y, n_head = gridDim.y, dh = threadIdx.x;
+    const size_t pb = ((size_t) j * n_head + h) * 32;
+    float s32[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s32[r] = partial[(pb + r) * 64 + dh];
+    double sumf = (double) wa_tree32(s32);
+    const int np = n_kv & ~31;
+    const wa_f16 * vp = vbase + (size_t) h * v_head_stride;
+    for (int c = np; c < n_kv; ++c) sumf += (double) (h2f(vp[(size_t) c * v_row_stride + dh]) * h2f(p_left[pb + (c - np)]));
+    out[(size_t) j * ldo + h * 64 + dh] = f2h((float) sumf);
+}
+
+void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
+                          const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
+                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out) {
+    if ((long) n_tokens * n_head >= 512) {
+        hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(256), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out);
+    } else {
+        hipLaunchKernelGGL((k_attn_exact<4>), dim3(n_head * 4, n_tokens), dim3(256), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out);
+        hipLaunchKernelGGL(k_attn_combine, dim3(n_tokens, n_head), dim3(64), 0, s, partial, p_left, vbase, v_head_stride, v_row_stride, n_kv,
+                           out, ldo);
+    }
+}

@@ -94,6 +94,8 @@ struct wa_model {
     wa_lin conv1;                         // w [d][3*n_mels -> padded to mult of 32], k-major (k*n_mels+ic)
     wa_lin conv2;                         // w [d][3*d], k-major (k*d+ic)
     int    conv1_kpad = 0;
+    const wa_f16 * conv1_g = nullptr;     // w [d][3*n_mels] in the file's (ggml im2col) order ic*3+k: reference-order path
+    const wa_f16 * conv2_g = nullptr;     // w [d][3*d]      likewise
     wa_ln  e_ln;
     std::vector<wa_enc_layer> enc;
     const float  * d_pe = nullptr;        // [n_text_ctx][d]
@@ -107,6 +109,7 @@ struct whisper_context {
     int64_t t_load_us = 0, t_start_us = 0;
     whisper_context_params params;
     int device = 0;
+    bool exact = true;                    // !params.flash_attn: encoder/prompt in the reference's summation order (bit-exact)
     wa_model model;
     wa_vocab vocab;
     whisper_state * state = nullptr;      // default state (only for the non-_no_state constructors)
@@ -210,7 +213,9 @@ struct whisper_state {
     wa_f16 * d_dao = nullptr;     // [mpad][d] f16
     wa_f16 * d_dff = nullptr;     // [mpad][4d] f16
     wa_f16 * d_dq  = nullptr;     // [mpad][d] f16 cross query
-    float  * d_scores = nullptr;  // [mpad][n_head][max(n_audio_ctx, kv size)] f32 scratch
+    float  * d_att_partial = nullptr; // [512][32][64] f32: P V partial-sum chains of (token, head) pairs (decode)
+    wa_f16 * d_att_pleft = nullptr;   // [512][32] f16: probabilities of the n_kv % 32 leftover cells
+    wa_f16 * d_im2col = nullptr;      // reference-order conv: [2T][3*n_mels] / [T][3d] f16
     float  * d_logits = nullptr;  // [mpad][n_vocab] f32
     int32_t * d_rows = nullptr;   // [mpad] row indices that need logits
     float  * d_aheads_qk = nullptr; // DTW capture

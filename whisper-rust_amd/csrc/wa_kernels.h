@@ -79,3 +79,17 @@ void wa_launch_dec_self_attn(hipStream_t stream, const wa_f16 * q, int ldq, cons
 void wa_launch_dec_cross_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kc, const wa_f16 * vc,
                               int tpad, int T, int n_head, int n_tokens, float scale, float * scores_scratch,
                               wa_f16 * out, int ldo, float * qk_out);
+
+// ---- reference-order kernels (wa_exact.hip): bit-identical to the reference's ggml-cpu AVX2 path ----
+void wa_launch_gemm_exact(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
+                          const wa_epi & e);
+void wa_launch_gemv_exact(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
+                          int M, int N, int K, const wa_epi & e);
+void wa_launch_im2col3(hipStream_t stream, const wa_f16 * src, int src_ld, int row0, int stride, int IC, int OL, wa_f16 * dst, int dst_ld);
+void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
+                               wa_f16 * out16, int ld16, float * out32, int ld32);
+// q [n_tokens][ldq] f16; K row c of head h at kbase + h*k_head_stride + c*k_row_stride (64 halfs), V likewise.
+// partial: f32 [n_tokens][n_head][32][64], p_left: f16 [n_tokens][n_head][32] (used when n_tokens*n_head < 512).
+void wa_launch_attn_exact(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
+                          const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
+                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out);

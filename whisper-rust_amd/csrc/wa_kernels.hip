@@ -6,106 +6,7 @@
 // (ggml-cpu.c:1331-1366, ggml.c:3929, whisper.cpp:2181-2202, vec.h:571-585).  Every kernel below
 // rounds at exactly those points; only the F32 summation ORDER differs (MFMA / wave reductions).
 // The file is compiled with -ffp-contract=off: an fma appears only where it is written.
-#include "wa_kernels.h"
-
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-typedef _Float16 h16;
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float    f32x4 __attribute__((ext_vector_type(4)));
-
-#define WAVE 64
-
-__device__ __forceinline__ float h2f(wa_f16 v) { union { wa_f16 u; h16 h; } c; c.u = v; return (float) c.h; }
-__device__ __forceinline__ wa_f16 f2h(float v) { union { wa_f16 u; h16 h; } c; c.h = (h16) v; return c.u; }   // RNE
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
-
-// ggml's vectorised expf (vec.h:774-811, the AVX2+FMA flavour the reference CPU path runs for all
-// but the last n%8 softmax elements), restated in scalar form with the same operation order.
-__device__ __forceinline__ float wa_expf(float x) {
-    const float r = 0x1.8p23f;
-    const float z = fmaf(x, 0x1.715476p+0f, r);
-    const float n = z - r;
-    const float b = fmaf(-n, 0x1.7f7d1cp-20f, fmaf(-n, 0x1.62e4p-1f, x));
-    const uint32_t e = __float_as_uint(z) << 23;
-    const float k = __uint_as_float(e + __float_as_uint(1.0f));
-    const float an = fabsf(n);
-    const float u = b * b;
-    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u,
-                         0x1.ffffecp-1f * b);
-    if (!(an > 126.0f)) return fmaf(j, k, k);
-    const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
-    const float s1 = __uint_as_float(g + 0x7f000000u);
-    const float s2 = __uint_as_float(e - g);
-    if (an > 192.0f) return s1 * s1;
-    return fmaf(s2, j, s2) * s1;
-}
-
-// GELU exactly as ggml_vec_gelu_f32 with GGML_GELU_FP16 (vec.h:571-585): table lookup on the F16
-// bits of x, identity above 10, zero below -10.  Result is an F32 that is exactly F16-representable
-// (or x itself for x >= 10).
-__device__ __forceinline__ float wa_gelu(float x, const wa_f16 * __restrict__ table) {
-    if (x <= -10.0f) return 0.0f;
-    if (x >=  10.0f) return x;
-    return h2f(table[f2h(x)]);
-}
-
-// =================================================================================================
-// GEMM epilogues (shared by the MFMA GEMM and the GEMV)
-// =================================================================================================
-template <int EPI>
-__device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float acc) {
-    float v = acc;
-    if (EPI != WA_EPI_F32 || e.bias) { if (e.bias) v = v + e.bias[n]; }
-    if (EPI == WA_EPI_F16) {
-        if (e.scale) v = v * e.scale[n];
-        ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
-    } else if (EPI == WA_EPI_ENC_QKV) {
-        if (n < e.split0) ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
-        else              ((wa_f16 *) e.out2)[(size_t) (n - e.split0) * e.ldo2 + m] = f2h(v);
-    } else if (EPI == WA_EPI_GELU_F16) {
-        ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(wa_gelu(v, e.gelu));
-    } else if (EPI == WA_EPI_RESID) {
-        ((float *) e.out)[(size_t) m * e.ldo + n] = v + e.resid[(size_t) m * e.ldr + n];
-    } else if (EPI == WA_EPI_CONV2) {
-        const float g = wa_gelu(v, e.gelu);
-        if (e.dbg) e.dbg[(size_t) m * e.ldo + n] = g;
-        ((float *) e.out)[(size_t) m * e.ldo + n] = e.resid[(size_t) m * e.ldr + n] + g;
-    } else if (EPI == WA_EPI_F32) {
-        ((float *) e.out)[(size_t) m * e.ldo + n] = v;
-    } else if (EPI == WA_EPI_CROSS_KV) {
-        // n = layer*2d + kv*d + head*64 + c ; aux0 = tpad, aux1 = d
-        if (e.scale) v = v * e.scale[n];
-        const int d = e.aux1, two_d = 2 * d;
-        const int il = n / two_d, r = n - il * two_d;
-        const int kv = r >= d, rr = kv ? r - d : r;
-        const int n_head = d >> 6, hd = rr >> 6, c = rr & 63;
-        wa_f16 * dst = (wa_f16 *) (kv ? e.out2 : e.out);
-        dst[(((size_t) il * n_head + hd) * e.aux0 + m) * 64 + c] = f2h(v);
-    } else if (EPI == WA_EPI_DEC_QKV) {
-        if (e.scale) v = v * e.scale[n];
-        if (n < e.split0)      ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
-        else if (n < e.split1) ((wa_f16 *) e.out2)[(size_t) (e.row_off + m) * e.ldo2 + (n - e.split0)] = f2h(v);
-        else                   ((wa_f16 *) e.out3)[(size_t) (e.row_off + m) * e.ldo3 + (n - e.split1)] = f2h(v);
-    }
-}
+#include "wa_device.h"
 
 // =================================================================================================
 // MFMA GEMM: C = A * W^T, both operands K-contiguous F16, F32 accumulate (v_mfma_f32_16x16x32_f16).

@@ -35,6 +35,7 @@ struct slot {             // where a named tensor goes
     int    type;          // expected ggml type: 0 f32, 1 f16
     int64_t ne[3];        // expected ne[] (fastest first)
     int    ld;            // kind 1: destination row stride in elements
+    size_t off2 = 0;      // kind 1: byte offset of the second, unpermuted copy (ggml im2col order)
     bool   seen = false;
 };
 
@@ -211,10 +212,13 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
     model.conv1_kpad = wa_pad(3 * hp.n_mels, 32);
     const size_t o_c1w = ab.take((size_t) d * model.conv1_kpad * H), o_c1b = ab.take(d * F);
     const size_t o_c2w = ab.take((size_t) d * 3 * d * H),            o_c2b = ab.take(d * F);
+    const size_t o_c1g = ab.take((size_t) d * 3 * hp.n_mels * H), o_c2g = ab.take((size_t) d * 3 * d * H);
     add("encoder.conv1.weight", 1, o_c1w, 1, 3, hp.n_mels, d, model.conv1_kpad);
     add("encoder.conv1.bias",   0, o_c1b, 0, 1, d, 1);
     add("encoder.conv2.weight", 1, o_c2w, 1, 3, d, d, 3 * d);
     add("encoder.conv2.bias",   0, o_c2b, 0, 1, d, 1);
+    slots["encoder.conv1.weight"].off2 = o_c1g;
+    slots["encoder.conv2.weight"].off2 = o_c2g;
     const ln_off o_eln = take_ln("encoder.ln_post");
 
     struct enc_off { ln_off attn_ln, mlp_ln; lin_off qkv, out, fc1, fc2; };
@@ -321,6 +325,7 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
             const int IC = (int) s.ne[1], OC = (int) s.ne[2];
             const wa_f16 * src = (const wa_f16 *) tmp.data();
             wa_f16 * dst = (wa_f16 *) (img.data() + s.off);
+            memcpy(img.data() + s.off2, tmp.data(), nbytes);
             for (int oc = 0; oc < OC; ++oc)
                 for (int ic = 0; ic < IC; ++ic)
                     for (int k = 0; k < 3; ++k) dst[(size_t) oc * s.ld + k * IC + ic] = src[((size_t) oc * IC + ic) * 3 + k];
@@ -356,6 +361,7 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
     model.e_pe = PF(o_epe);
     model.conv1 = LIN(lin_off{ o_c1w, o_c1b, 0 }, d, model.conv1_kpad);
     model.conv2 = LIN(lin_off{ o_c2w, o_c2b, 0 }, d, 3 * d);
+    model.conv1_g = PH(o_c1g); model.conv2_g = PH(o_c2g);
     model.e_ln = LN(o_eln);
     model.enc.resize(Le);
     for (int i = 0; i < Le; ++i) {
