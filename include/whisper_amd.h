@@ -455,6 +455,11 @@ WHISPER_API void whisper_amd_gelu_table_f16(uint16_t * dst);
  * event timing (bench.py) and stream-ordered hand-off of device PCM buffers. */
 WHISPER_API void * whisper_amd_state_stream(struct whisper_state * state);
 
+/* Decode-loop bookkeeping of decoder `j` after whisper_full* (for tests: compares the loop's internal decisions with
+ * the reference even when no segment was emitted): out = { failed, completed, has_ts, seek_delta, result_len,
+ * avg_logprobs, entropy, no_speech_prob }; ids receives up to max_ids token ids; returns the token count. */
+WHISPER_API int whisper_amd_decoder_info(struct whisper_state * state, int j, double out[8], int32_t * ids, int max_ids);
+
 /* Measurement helper (bench.py): replays the single-token decoder pass `n_iters` times back to back on the
  * state's stream between two HIP events and returns the average DEVICE time of one decode step in ms.
  * Needs a prior whisper_encode*; touches KV cell `n_past` of the state.  0 on success. */

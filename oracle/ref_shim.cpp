@@ -77,3 +77,15 @@ void ref_shim_gelu_table_f16(uint16_t * dst /*[65536]*/) {
 }
 
 } // extern "C"
+
+// decoder bookkeeping after whisper_full* (whisper.cpp:816-853): lets the tests compare the decode loop's
+// internal decisions (failed / completed / result_len / seek_delta / scores) and the raw token sequence
+// even when no segment was emitted.
+extern "C" int ref_shim_decoder_info(struct whisper_state * st, int j, double * out /*[8]*/, int32_t * ids, int max_ids) {
+    const auto & d = st->decoders[j];
+    out[0] = d.failed; out[1] = d.completed; out[2] = d.has_ts; out[3] = d.seek_delta; out[4] = d.sequence.result_len;
+    out[5] = d.sequence.avg_logprobs; out[6] = d.sequence.entropy; out[7] = st->no_speech_prob;
+    const int n = (int) d.sequence.tokens.size();
+    for (int i = 0; i < n && i < max_ids; ++i) ids[i] = d.sequence.tokens[i].id;
+    return n;
+}

@@ -670,6 +670,16 @@ void whisper_amd_gelu_table_f16(uint16_t * dst) {
 }
 void * whisper_amd_state_stream(struct whisper_state * st) { return (void *) st->stream; }
 
+int whisper_amd_decoder_info(struct whisper_state * st, int j, double out[8], int32_t * ids, int max_ids) {
+    if (!st || j < 0 || j >= WA_MAX_DECODERS) return -1;
+    const auto & d = st->decoders[j];
+    out[0] = d.failed; out[1] = d.completed; out[2] = d.has_ts; out[3] = d.seek_delta; out[4] = d.sequence.result_len;
+    out[5] = d.sequence.avg_logprobs; out[6] = d.sequence.entropy; out[7] = st->no_speech_prob;
+    const int n = (int) d.sequence.tokens.size();
+    for (int i = 0; i < n && i < max_ids; ++i) ids[i] = d.sequence.tokens[i].id;
+    return n;
+}
+
 int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state ** states, int n_chunks, struct whisper_full_params params,
                            const float * const * samples, const int * n_samples) {
     // v1: sequential over the chunks' own states (lock-step batched decode is the planned form)

@@ -75,6 +75,15 @@ void wa_kv_seq_cp(wa_kv_cache & c, int32_t src, int32_t dst, int32_t p0, int32_t
 // -------------------------------------------------------------------------------------------------
 // small-M products stream the weights once (GEMV, HBM-bound, reference summation order);
 // larger M (prompt): reference-order VALU GEMM, or the MFMA GEMM when flash_attn is on
+// LayerNorm followed by a projection: one fused launch for M <= 8, LayerNorm kernel + GEMM otherwise
+static void ln_linear(hipStream_t s, bool exact, wa_epi_mode mode, const float * x, int d, const wa_ln & ln, float eps, wa_f16 * xn, const wa_lin & L,
+                      int M, const int32_t * rows, const wa_epi & e) {
+    if (M <= 8) { wa_launch_ln_gemv_exact(s, mode, x, d, rows, ln.w, ln.b, eps, L.w, L.n_in, M, L.n_out, L.n_in, e); return; }
+    wa_launch_layernorm_exact(s, x, d, M, d, ln.w, ln.b, eps, xn, d, nullptr, 0);
+    if (exact) wa_launch_gemm_exact(s, mode, xn, d, L.w, L.n_in, M, L.n_out, L.n_in, e);
+    else       wa_launch_gemm(s, mode, xn, d, L.w, L.n_in, M, L.n_out, L.n_in, e);
+}
+
 static void linear(hipStream_t s, bool exact, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
     if (M <= 8)     wa_launch_gemv_exact(s, mode, A, lda, nullptr, L.w, L.n_in, M, L.n_out, L.n_in, e);   // reference order is free here
     else if (exact) wa_launch_gemm_exact(s, mode, A, lda, L.w, L.n_in, M, L.n_out, L.n_in, e);
@@ -102,12 +111,11 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
     for (int il = 0; il < hp.n_text_layer; ++il) {
         const auto & L = m.dec[il];
         // ---- masked self-attention ----
-        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
-        {   // fused q|k|v: q scaled -> d_dq ; k scaled, v -> straight into their KV cells [kv_head, kv_head + n_tokens)
+        {   // LayerNorm + fused q|k|v: q scaled -> d_dq ; k scaled, v -> straight into their KV cells [kv_head, kv_head + n_tokens)
             wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
             e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
             e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
-            linear(s, ctx.exact, WA_EPI_DEC_QKV, st.d_dxn, d, L.qkv, n_tokens, e);
+            ln_linear(s, ctx.exact, WA_EPI_DEC_QKV, st.d_dx, d, L.attn_ln, hp.eps, st.d_dxn, L.qkv, n_tokens, nullptr, e);
         }
         wa_launch_attn_exact(s, st.d_dq, d, kv.k + il * kv_layer, 64, d, kv.v + il * kv_layer, 64, d, H, n_tokens, n_kv, mask, 1.0f,
                              st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr);
@@ -116,10 +124,9 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
             linear(s, ctx.exact, WA_EPI_RESID, st.d_dao, d, L.out, n_tokens, e);
         }
         // ---- cross-attention over the encoder K/V ----
-        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.cross_ln.w, L.cross_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
         {
             wa_epi e; e.bias = L.cross_q.b; e.out = st.d_dq; e.ldo = d;
-            linear(s, ctx.exact, WA_EPI_F16, st.d_dxn, d, L.cross_q, n_tokens, e);
+            ln_linear(s, ctx.exact, WA_EPI_F16, st.d_dx, d, L.cross_ln, hp.eps, st.d_dxn, L.cross_q, n_tokens, nullptr, e);
         }
         float * qk_out = nullptr;
         if (save_aheads && st.d_aheads_qk && il < (int) st.aheads.size() && !st.aheads[il].empty())
@@ -131,23 +138,20 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
             linear(s, ctx.exact, WA_EPI_RESID, st.d_dao, d, L.cross_out, n_tokens, e);
         }
         // ---- feed-forward ----
-        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
         {
             wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_dff; e.ldo = 4 * d;
-            linear(s, ctx.exact, WA_EPI_GELU_F16, st.d_dxn, d, L.fc1, n_tokens, e);
+            ln_linear(s, ctx.exact, WA_EPI_GELU_F16, st.d_dx, d, L.mlp_ln, hp.eps, st.d_dxn, L.fc1, n_tokens, nullptr, e);
         }
         {
             wa_epi e; e.bias = L.fc2.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
             linear(s, ctx.exact, WA_EPI_RESID, st.d_dff, 4 * d, L.fc2, n_tokens, e);
         }
     }
-    wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, m.d_ln.w, m.d_ln.b, hp.eps, st.d_dxn, d, nullptr, 0);
-
-    // logits = token_embedding . x for the flagged rows only (the reference computes all rows and
+    // final LayerNorm + logits = token_embedding . x, for the flagged rows only (the reference computes all rows and
     // copies out the flagged ones, whisper.cpp:2835, 2965-2971)
     if (n_rows) {
         wa_epi e; e.out = st.d_logits; e.ldo = n_vocab;
-        wa_launch_gemv_exact(s, WA_EPI_F32, st.d_dxn, d, st.d_rows, m.d_te, d, n_rows, n_vocab, d, e);
+        wa_launch_ln_gemv_exact(s, WA_EPI_F32, st.d_dx, d, st.d_rows, m.d_ln.w, m.d_ln.b, hp.eps, m.d_te, d, n_rows, n_vocab, d, e);
     }
 }
 

@@ -112,22 +112,121 @@ void wa_launch_gemm_exact(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int
 }
 
 // =================================================================================================
+// LayerNorm in reference order (ops.cpp:3225-3242): one wave per row.
+// =================================================================================================
+// The reference sums a row in index order in F64 (ops.cpp:3225-3237).  A wave sums it in another order; the two
+// F64 results can differ by at most delta = 2 n u sum|x| (u = 2^-53).  Rounding to F32 after the division is
+// monotonic, so when (S - delta)/n and (S + delta)/n round to the SAME float, that float is the reference's
+// value whatever its order was.  Otherwise (probability ~ n 2^-27 per row) one lane redoes the sum in index order.
+__device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out) {
+    const double delta = 2.0 * (double) n * 0x1p-53 * A * 1.000001;
+    const float lo = (float) ((S - delta) / (double) n), hi = (float) ((S + delta) / (double) n);
+    out = lo;
+    return lo == hi;
+}
+
+// LayerNorm statistics of one row by one wave, reference-order semantics.  The row is read ONCE into registers
+// (NPL values per lane, d <= 64 * NPL); returns mean and scale.
+#define LN_NPL 20
+__device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d, float eps, int lane, float (&xv)[LN_NPL], float & mean, float & scale) {
+    double s = 0.0, a = 0.0;
+#pragma unroll
+    for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? xr[i] : 0.0f; }
+#pragma unroll
+    for (int k = 0; k < LN_NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }    // padding adds exact zeros
+    s = wave_sum_d(s); a = wave_sum_d(a);
+    if (!wa_sum_certain(s, a, d, mean)) {
+        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) t += (double) xr[i]; s = t; }
+        s = __shfl(s, 0, WAVE);
+        mean = (float) (s / (double) d);
+    }
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < LN_NPL; ++k) if (lane + 64 * k < d) { const float v = xv[k] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum_d(s2);
+    float variance;
+    if (!wa_sum_certain(s2, s2, d, variance)) {
+        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) { const float v = xr[i] - mean; t += (double) (v * v); } s2 = t; }
+        s2 = __shfl(s2, 0, WAVE);
+        variance = (float) (s2 / (double) d);
+    }
+    scale = 1.0f / sqrtf(variance + eps);
+}
+
+__global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
+                                                         const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
+                                                         float * __restrict__ out32, int ld32) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float * xr = x + (size_t) row * ldx;
+    float xv[LN_NPL], mean, scale;
+    wa_ln_stats(xr, d, eps, lane, xv, mean, scale);
+#pragma unroll
+    for (int k = 0; k < LN_NPL; ++k) {
+        const int i = lane + 64 * k;
+        if (i < d) {
+            float y = xv[k] - mean;
+            y = y * scale;
+            y = y * w[i];
+            y = y + b[i];
+            if (out16) out16[(size_t) row * ld16 + i] = f2h(y);
+            if (out32) out32[(size_t) row * ld32 + i] = y;
+        }
+    }
+}
+void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
+                               wa_f16 * out16, int ld16, float * out32, int ld32) {
+    hipLaunchKernelGGL(k_layernorm_exact, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32);
+}
+
+// =================================================================================================
 // GEMV (M <= 8 tokens, K % 32 == 0): weight streaming, HBM-bound.  8 lanes per output row: lane u owns
 // elements 4u..4u+3 of every 32-element block, i.e. partial sums (j = u/2, l = 4(u%2)+e); the xor-4 / xor-2 /
 // xor-1 exchanges then reproduce the reference's (s0+s2)+(s1+s3), l<->l+4 and final pairings exactly.
 // Activations staged once per block in LDS; weights go straight from HBM to VGPRs (8 B per lane per step).
 // =================================================================================================
+// Optional fused prologue (ln.x != null): the activations are LayerNorm(x) of F32 rows, normalised and rounded to
+// F16 by every block for itself (M <= 8 rows: cheaper than a separate launch on the latency-bound decode step).
+struct wa_ln_in { const float * x = nullptr; int ldx = 0; const float * w = nullptr; const float * b = nullptr; float eps = 0.f; };
+
+#define GEMV_BATCH 24      // weight loads kept in flight per lane (8 B each)
+
 template <int MT, int EPI>
-__global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ A, int lda, const int32_t * __restrict__ rows,
+__global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ A, int lda, const int32_t * __restrict__ rows, wa_ln_in ln,
                                                     const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
     extern __shared__ __attribute__((aligned(16))) wa_f16 xs[];   // [MT][K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kc = K >> 3;
-    for (int c = tid; c < MT * kc; c += 128) {
-        const int m = c / kc, cc = c - m * kc;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < M) { const int src = rows ? rows[m] : m; v = *(const uint4 *) (A + (size_t) src * lda + cc * 8); }
-        *(uint4 *) (&xs[(size_t) m * K + cc * 8]) = v;
+    if (ln.x) {
+        for (int m = wave; m < MT; m += 2) {
+            if (m < M) {
+                const int src = rows ? rows[m] : m;
+                const float * xr = ln.x + (size_t) src * ln.ldx;
+                float xv[LN_NPL], mean, scale;
+                wa_ln_stats(xr, K, ln.eps, lane, xv, mean, scale);
+#pragma unroll
+                for (int k = 0; k < LN_NPL; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < K) {
+                        float y = xv[k] - mean;
+                        y = y * scale;
+                        y = y * ln.w[i];
+                        y = y + ln.b[i];
+                        xs[(size_t) m * K + i] = f2h(y);
+                    }
+                }
+            } else {
+                for (int i = lane; i < K; i += 64) xs[(size_t) m * K + i] = 0;
+            }
+        }
+    } else {
+        const int kc = K >> 3;
+        for (int c = tid; c < MT * kc; c += 128) {
+            const int m = c / kc, cc = c - m * kc;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < M) { const int src = rows ? rows[m] : m; v = *(const uint4 *) (A + (size_t) src * lda + cc * 8); }
+            *(uint4 *) (&xs[(size_t) m * K + cc * 8]) = v;
+        }
     }
     __syncthreads();
     const int u = lane & 7, slot = lane >> 3;
@@ -141,19 +240,28 @@ __global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ 
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[m][i] = 0.0f;
-#pragma unroll 4
-        for (int s = 0; s < nsteps; ++s) {
-            const uint2 wv = *(const uint2 *) (wrow + s * 32);
-            const wa_f16 * w4 = (const wa_f16 *) &wv;
-            const float w0 = h2f(w4[0]), w1 = h2f(w4[1]), w2 = h2f(w4[2]), w3 = h2f(w4[3]);
+        for (int s0 = 0; s0 < nsteps; s0 += GEMV_BATCH) {
+            uint2 wv[GEMV_BATCH];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const uint2 xv = *(const uint2 *) (&xs[(size_t) m * K + s * 32 + 4 * u]);
-                const wa_f16 * x4 = (const wa_f16 *) &xv;
-                acc[m][0] = fmaf(w0, h2f(x4[0]), acc[m][0]);
-                acc[m][1] = fmaf(w1, h2f(x4[1]), acc[m][1]);
-                acc[m][2] = fmaf(w2, h2f(x4[2]), acc[m][2]);
-                acc[m][3] = fmaf(w3, h2f(x4[3]), acc[m][3]);
+            for (int b = 0; b < GEMV_BATCH; ++b) {
+                const int s = s0 + b < nsteps ? s0 + b : nsteps - 1;
+                wv[b] = *(const uint2 *) (wrow + s * 32);
+            }
+#pragma unroll
+            for (int b = 0; b < GEMV_BATCH; ++b) {
+                if (s0 + b < nsteps) {
+                    const wa_f16 * w4 = (const wa_f16 *) &wv[b];
+                    const float w0 = h2f(w4[0]), w1 = h2f(w4[1]), w2 = h2f(w4[2]), w3 = h2f(w4[3]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const uint2 xv = *(const uint2 *) (&xs[(size_t) m * K + (s0 + b) * 32 + 4 * u]);
+                        const wa_f16 * x4 = (const wa_f16 *) &xv;
+                        acc[m][0] = fmaf(w0, h2f(x4[0]), acc[m][0]);
+                        acc[m][1] = fmaf(w1, h2f(x4[1]), acc[m][1]);
+                        acc[m][2] = fmaf(w2, h2f(x4[2]), acc[m][2]);
+                        acc[m][3] = fmaf(w3, h2f(x4[3]), acc[m][3]);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -173,14 +281,14 @@ __global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ 
 }
 
 template <int MT>
-static void gemv_exact_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
-                                int M, int N, int K, const wa_epi & e) {
+static void gemv_exact_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_ln_in & ln,
+                                const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
     int grid = (N + 15) / 16;
     if (grid > 4096) grid = 4096;
     const size_t lds = (size_t) MT * K * sizeof(wa_f16);
 #define WA_CASE(E) case E: { \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_gemv_exact<MT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL((k_gemv_exact<MT, E>), dim3(grid), dim3(128), lds, s, A, lda, rows, W, ldw, M, N, K, e); } break;
+        hipLaunchKernelGGL((k_gemv_exact<MT, E>), dim3(grid), dim3(128), lds, s, A, lda, rows, ln, W, ldw, M, N, K, e); } break;
     switch (mode) {
         WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_GELU_F16) WA_CASE(WA_EPI_RESID) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_DEC_QKV)
         default: break;
@@ -188,12 +296,23 @@ static void gemv_exact_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * 
 #undef WA_CASE
 }
 
+static void gemv_exact_any(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_ln_in & ln,
+                           const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
+    if (M <= 1)      gemv_exact_dispatch<1>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
+    else if (M <= 2) gemv_exact_dispatch<2>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
+    else if (M <= 4) gemv_exact_dispatch<4>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
+    else             gemv_exact_dispatch<8>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
+}
+
 void wa_launch_gemv_exact(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
                           int M, int N, int K, const wa_epi & e) {
-    if (M <= 1)      gemv_exact_dispatch<1>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
-    else if (M <= 2) gemv_exact_dispatch<2>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
-    else if (M <= 4) gemv_exact_dispatch<4>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
-    else             gemv_exact_dispatch<8>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
+    gemv_exact_any(stream, mode, A, lda, rows, wa_ln_in(), W, ldw, M, N, K, e);
+}
+
+void wa_launch_ln_gemv_exact(hipStream_t stream, wa_epi_mode mode, const float * x, int ldx, const int32_t * rows, const float * ln_w,
+                             const float * ln_b, float eps, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
+    wa_ln_in ln; ln.x = x; ln.ldx = ldx; ln.w = ln_w; ln.b = ln_b; ln.eps = eps;
+    gemv_exact_any(stream, mode, nullptr, 0, rows, ln, W, ldw, M, N, K, e);
 }
 
 // =================================================================================================
@@ -216,75 +335,6 @@ void wa_launch_im2col3(hipStream_t s, const wa_f16 * src, int src_ld, int row0, 
 }
 
 // =================================================================================================
-// LayerNorm in reference order (ops.cpp:3225-3242): one wave per row.
-// =================================================================================================
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, WAVE); v = v > t ? v : t; }
-    return v;
-}
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, WAVE); v = v < t ? v : t; }
-    return v;
-}
-// biased exponent of a non-zero float; denormals report -1000 so that the certificate fails
-__device__ __forceinline__ int f32_exp(float x) { const int e = (__float_as_uint(x) >> 23) & 0xff; return e == 0 ? -1000 : e; }
-
-__global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
-                                                         const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
-                                                         float * __restrict__ out32, int ld32) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    const float * xr = x + (size_t) row * ldx;
-    // Every partial sum of addends whose exponents span <= 18 binades (d <= 2048) is exact in F64, so the
-    // parallel sum equals the reference's index-order sum; otherwise one lane walks the row in order.
-    double s = 0.0;
-    int emax = -2000, emin = 2000;
-    for (int i = lane; i < d; i += 64) {
-        const float v = xr[i];
-        s += (double) v;
-        if (v != 0.0f) { const int e = f32_exp(v); emax = e > emax ? e : emax; emin = e < emin ? e : emin; }
-    }
-    s = wave_sum_d(s);
-    emax = wave_max_i(emax); emin = wave_min_i(emin);
-    if (emax - emin > 18) {
-        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) t += (double) xr[i]; s = t; }
-        s = __shfl(s, 0, WAVE);
-    }
-    const float mean = (float) (s / (double) d);
-    double s2 = 0.0;
-    emax = -2000; emin = 2000;
-    for (int i = lane; i < d; i += 64) {
-        const float v = xr[i] - mean;
-        const float vv = v * v;
-        s2 += (double) vv;
-        if (vv != 0.0f) { const int e = f32_exp(vv); emax = e > emax ? e : emax; emin = e < emin ? e : emin; }
-    }
-    s2 = wave_sum_d(s2);
-    emax = wave_max_i(emax); emin = wave_min_i(emin);
-    if (emax - emin > 18) {
-        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) { const float v = xr[i] - mean; t += (double) (v * v); } s2 = t; }
-        s2 = __shfl(s2, 0, WAVE);
-    }
-    const float variance = (float) (s2 / (double) d);
-    const float scale = 1.0f / sqrtf(variance + eps);
-    for (int i = lane; i < d; i += 64) {
-        float y = xr[i] - mean;
-        y = y * scale;
-        y = y * w[i];
-        y = y + b[i];
-        if (out16) out16[(size_t) row * ld16 + i] = f2h(y);
-        if (out32) out32[(size_t) row * ld32 + i] = y;
-    }
-}
-void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
-                               wa_f16 * out16, int ld16, float * out32, int ld32) {
-    hipLaunchKernelGGL(k_layernorm_exact, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32);
-}
-
-// =================================================================================================
 // Attention in reference order, d_head = 64, one (query, head) per block (x RS residue splits):
 //   scores  s[c] = vec_dot_f16(64; K[c], q) -> * scale (+ mask)                 (whisper.cpp:2636 / 2189 / 2732)
 //   softmax exactly as ops.cpp:4792-4818                                        (F32 probabilities)
@@ -294,16 +344,20 @@ void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int
 // per (query, head) to put more CUs on a single decode token and leaves the tree to k_attn_combine.
 // =================================================================================================
 #define ATT_MAXKV 4096
+#define ATT_THREADS 512
+#define ATT_KB 6            // keys per lane group whose K loads are issued together
 
 template <int RS>
-__global__ __launch_bounds__(256) void k_attn_exact(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
-                                                    int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
-                                                    int n_kv, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
-                                                    wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out) {
+__global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
+                                                            int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
+                                                            int n_kv, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
+                                                            wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out) {
+    constexpr int NW = ATT_THREADS / 64;
     __shared__ float sc[ATT_MAXKV];
     __shared__ wa_f16 p16[ATT_MAXKV];
     __shared__ float gs[ATT_MAXKV / 8];
-    __shared__ float red[4];
+    __shared__ float red[NW];
+    __shared__ double redd[NW];
     __shared__ float s_inv;
     __shared__ __attribute__((aligned(16))) wa_f16 qs[64];
     __shared__ float part[RS == 1 ? 32 * 64 : 1];
@@ -318,47 +372,86 @@ __global__ __launch_bounds__(256) void k_attn_exact(const wa_f16 * __restrict__ 
     if (tid < 64) qs[tid] = q[(size_t) j * ldq + h * 64 + tid];
     __syncthreads();
 
-    // ---- scores ----
+    // ---- scores: 4 lanes per key; lane a owns partial sums j = a (elements 8a..8a+7 and 32+8a..32+8a+7) ----
     float lmax = -INFINITY;
-    for (int c = tid; c < n_kv; c += 256) {
-        const wa_f16 * kr = kp + (size_t) c * k_row_stride;
-        uint4 kv[8];
+    {
+        const int a = tid & 3, kslot = tid >> 2;                 // 128 keys per pass
+        float qa[8], qb[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) kv[i] = *(const uint4 *) (kr + i * 8);
-        const wa_f16 * k64 = (const wa_f16 *) kv;
-        float s[32];
+        for (int l = 0; l < 8; ++l) { qa[l] = h2f(qs[8 * a + l]); qb[l] = h2f(qs[32 + 8 * a + l]); }
+        for (int c0 = 0; c0 < n_kv; c0 += (ATT_THREADS / 4) * ATT_KB) {
+            uint4 ka[ATT_KB], kb[ATT_KB];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) s[i] = fmaf(h2f(k64[i]), h2f(qs[i]), 0.0f);
+            for (int b = 0; b < ATT_KB; ++b) {
+                int c = c0 + b * (ATT_THREADS / 4) + kslot; c = c < n_kv ? c : n_kv - 1;
+                const wa_f16 * kr = kp + (size_t) c * k_row_stride;
+                ka[b] = *(const uint4 *) (kr + 8 * a);
+                kb[b] = *(const uint4 *) (kr + 32 + 8 * a);
+            }
 #pragma unroll
-        for (int i = 0; i < 32; ++i) s[i] = fmaf(h2f(k64[32 + i]), h2f(qs[32 + i]), s[i]);
-        float a = wa_tree32(s) * scale;
-        if (mrow && mrow[c]) a = -INFINITY;
-        sc[c] = a;
-        lmax = fmaxf(lmax, a);
+            for (int b = 0; b < ATT_KB; ++b) {
+                const int c = c0 + b * (ATT_THREADS / 4) + kslot;
+                const wa_f16 * k8a = (const wa_f16 *) &ka[b], * k8b = (const wa_f16 *) &kb[b];
+                float v[8];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    float t = fmaf(h2f(k8a[l]), qa[l], 0.0f);
+                    t = fmaf(h2f(k8b[l]), qb[l], t);
+                    t = t + __shfl_xor(t, 2, WAVE);          // s[j] + s[j+2]
+                    v[l] = t + __shfl_xor(t, 1, WAVE);       // (s0+s2) + (s1+s3)
+                }
+                const float t0 = v[0] + v[4], t1 = v[1] + v[5], t2 = v[2] + v[6], t3 = v[3] + v[7];
+                float r = ((t0 + t1) + (t2 + t3)) * scale;
+                if (c < n_kv) {
+                    if (mrow && mrow[c]) r = -INFINITY;
+                    if (a == 0) sc[c] = r;
+                    lmax = fmaxf(lmax, r);
+                }
+            }
+        }
     }
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
 
     // ---- exp: polynomial for the multiple-of-8 body, libm expf for the tail ----
     const int n8 = n_kv & ~7;
-    for (int c = tid; c < n_kv; c += 256) sc[c] = c < n8 ? wa_expf(sc[c] - mx) : wa_expf_libm(sc[c] - mx);
+    for (int c = tid; c < n_kv; c += ATT_THREADS) sc[c] = c < n8 ? wa_expf(sc[c] - mx) : wa_expf_libm(sc[c] - mx);
     __syncthreads();
-    for (int g = tid; g < (n8 >> 3); g += 256) {
+    for (int g = tid; g < (n8 >> 3); g += ATT_THREADS) {
         const float * v = &sc[g * 8];
         gs[g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
     }
     __syncthreads();
-    if (tid == 0) {                       // F64 running sum in group order (vec.cpp:278-305)
-        double sum = 0.0;
-        for (int g = 0; g < (n8 >> 3); ++g) sum += (double) gs[g];
-        for (int c = n8; c < n_kv; ++c) sum += (double) sc[c];
-        s_inv = (float) (1.0 / sum);
+    {   // F64 running sum in group order (vec.cpp:278-305): summed in parallel, accepted when the order cannot matter
+        // (all terms >= 0: two orders differ by <= 2 n u S; 1/S -> F32 is monotonic), else redone in order by one lane.
+        double ps = 0.0;
+        const int ng = n8 >> 3;
+        for (int g = tid; g < ng; g += ATT_THREADS) ps += (double) gs[g];
+        for (int c = n8 + tid; c < n_kv; c += ATT_THREADS) ps += (double) sc[c];
+        ps = wave_sum_d(ps);
+        if (lane == 0) redd[wave] = ps;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += redd[w];
+            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
+            const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
+            if (ilo != ihi) {
+                sum = 0.0;
+                for (int g = 0; g < ng; ++g) sum += (double) gs[g];
+                for (int c = n8; c < n_kv; ++c) sum += (double) sc[c];
+                s_inv = (float) (1.0 / sum);
+            } else s_inv = ilo;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const float inv = s_inv;
-    for (int c = tid; c < n_kv; c += 256) {
+    for (int c = tid; c < n_kv; c += ATT_THREADS) {
         const float p = sc[c] * inv;
         if (qk_out && rs == 0) qk_out[((size_t) j * n_head + h) * n_kv + c] = p;
         p16[c] = f2h(p);
@@ -367,17 +460,27 @@ __global__ __launch_bounds__(256) void k_attn_exact(const wa_f16 * __restrict__ 
 
     // ---- P V: chains r = c mod 32, lane = dh ----
     const int np = n_kv & ~31, nsteps = np >> 5;
-    constexpr int RPW = 32 / RS / 4;      // residues per wave
+    constexpr int RPW = 32 / RS / NW;     // residues per wave
     float acc[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) acc[i] = 0.0f;
     const int r0 = rs * (32 / RS) + wave * RPW;
-    for (int s = 0; s < nsteps; ++s) {
+    constexpr int CB = 16 / RPW > 1 ? 16 / RPW : 1;       // steps whose V loads are issued together
+    for (int s0 = 0; s0 < nsteps; s0 += CB) {
+        wa_f16 vv[CB][RPW];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int c = s * 32 + r0 + i;
-            acc[i] = fmaf(h2f(vp[(size_t) c * v_row_stride + lane]), h2f(p16[c]), acc[i]);
-        }
+        for (int b = 0; b < CB; ++b)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int sidx = s0 + b < nsteps ? s0 + b : nsteps - 1;
+                vv[b][i] = vp[(size_t) (sidx * 32 + r0 + i) * v_row_stride + lane];
+            }
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+            if (s0 + b < nsteps) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) acc[i] = fmaf(h2f(vv[b][i]), h2f(p16[(s0 + b) * 32 + r0 + i]), acc[i]);
+            }
     }
     if (RS == 1) {
 #pragma unroll
@@ -408,9 +511,16 @@ __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ 
 #pragma unroll
     for (int r = 0; r < 32; ++r) s32[r] = partial[(pb + r) * 64 + dh];
     double sumf = (double) wa_tree32(s32);
-    const int np = n_kv & ~31;
+    const int np = n_kv & ~31, nl = n_kv - np;
     const wa_f16 * vp = vbase + (size_t) h * v_head_stride;
-    for (int c = np; c < n_kv; ++c) sumf += (double) (h2f(vp[(size_t) c * v_row_stride + dh]) * h2f(p_left[pb + (c - np)]));
+    float prod[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {     // loads first (independent), ordered F64 accumulation after
+        const int cc = c < nl ? c : 0;
+        prod[c] = h2f(vp[(size_t) (np + cc) * v_row_stride + dh]) * h2f(p_left[pb + cc]);
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
     out[(size_t) j * ldo + h * 64 + dh] = f2h((float) sumf);
 }
 
@@ -418,10 +528,10 @@ void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
                           float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out) {
     if ((long) n_tokens * n_head >= 512) {
-        hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(256), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
+        hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
                            v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out);
     } else {
-        hipLaunchKernelGGL((k_attn_exact<4>), dim3(n_head * 4, n_tokens), dim3(256), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
+        hipLaunchKernelGGL((k_attn_exact<4>), dim3(n_head * 4, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
                            v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out);
         hipLaunchKernelGGL(k_attn_combine, dim3(n_tokens, n_head), dim3(64), 0, s, partial, p_left, vbase, v_head_stride, v_row_stride, n_kv,
                            out, ldo);

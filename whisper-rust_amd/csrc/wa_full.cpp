@@ -25,9 +25,12 @@ const char * const k_non_speech[] = {   // whisper.cpp:6102-6107
 };
 
 // log-softmax / softmax over the filtered logits (whisper.cpp:6109-6143): sequential F32 sums
-void compute_logprobs(const float * logits, int n, float * logprobs) {
+// `n_max` elements are scanned for the maximum: the reference takes it over the WHOLE vector it is handed, which
+// for the no-speech probe is every row of the prompt's logits buffer, not just the n it normalises (whisper.cpp:6113).
+void compute_logprobs(const float * logits, int n, float * logprobs, size_t n_max = 0) {
     float mx = logits[0];
-    for (int i = 1; i < n; ++i) if (logits[i] > mx) mx = logits[i];
+    const size_t nm = n_max > (size_t) n ? n_max : (size_t) n;
+    for (size_t i = 1; i < nm; ++i) if (logits[i] > mx) mx = logits[i];
     float lse = 0.0f;
     for (int i = 0; i < n; ++i) if (logits[i] > -INFINITY) lse += expf(logits[i] - mx);
     lse = logf(lse) + mx;
@@ -336,12 +339,12 @@ int runner::run(const float * samples, int n_samples) {
                 prep_batch(prompt.data(), (int) prompt.size(), 0, 0);
                 if (!wa_decode(*ctx, *st, st->batch, false, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -8; }
 
-                {   // no-speech probability from the unfiltered first logits (whisper.cpp:7124-7134).
-                    // NB the reference passes state->logits here, whose first n_vocab entries are row 0 of the
-                    // prompt decode - NOT the flagged last row - unless the prompt has one token. We mirror that:
-                    // row 0 holds zeros (never written) when the prompt is longer than one token.
+                {   // no-speech probability "from the first logits" (whisper.cpp:7124-7134).  Mirrored quirks of the
+                    // reference: it normalises ROW 0 of state->logits - which only the flagged LAST row of a prompt decode
+                    // writes, so row 0 keeps whatever an earlier call left there (zeros on a fresh state) - and takes the
+                    // soft-max shift from the maximum over ALL rows, which can underflow every term and yield +inf.
                     std::vector<float> lp(n_vocab), pr(n_vocab);
-                    compute_logprobs(st->logits.data(), n_vocab, lp.data());
+                    compute_logprobs(st->logits.data(), n_vocab, lp.data(), st->logits.size());
                     compute_probs(st->logits.data(), n_vocab, lp.data(), pr.data());
                     st->no_speech_prob = pr[vocab.token_nosp];
                 }

@@ -85,6 +85,9 @@ void wa_launch_gemm_exact(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A
                           const wa_epi & e);
 void wa_launch_gemv_exact(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
                           int M, int N, int K, const wa_epi & e);
+// Same GEMV with LayerNorm(x) fused in front (x F32 [M][K]): one launch instead of two on the decode step.
+void wa_launch_ln_gemv_exact(hipStream_t stream, wa_epi_mode mode, const float * x, int ldx, const int32_t * rows, const float * ln_w,
+                             const float * ln_b, float eps, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e);
 void wa_launch_im2col3(hipStream_t stream, const wa_f16 * src, int src_ld, int row0, int stride, int IC, int OL, wa_f16 * dst, int dst_ld);
 void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
                                wa_f16 * out16, int ld16, float * out32, int ld32);
