@@ -19,8 +19,9 @@ GGML_MAGIC = 0x67676D6C
 # (n_audio_state, n_audio_head, n_audio_layer, n_text_layer, n_mels, n_vocab)
 SHAPES = {
     # tiny synthetic shapes for fast CPU-oracle tests (not real Whisper sizes)
-    "s64":    dict(d=64,   heads=2,  enc=2,  dec=3,  n_mels=80,  n_vocab=51865),
+    "s64":    dict(d=64,   heads=1,  enc=2,  dec=3,  n_mels=80,  n_vocab=51865),
     "s128":   dict(d=128,  heads=2,  enc=3,  dec=4,  n_mels=80,  n_vocab=51865),
+    "s192":   dict(d=192,  heads=3,  enc=2,  dec=2 + 1, n_mels=80, n_vocab=51865),   # d not a multiple of 128: tile guards
     # real Whisper shapes (SURVEY.md §8 header)
     "tiny":   dict(d=384,  heads=6,  enc=4,  dec=4,  n_mels=80,  n_vocab=51865),
     "base":   dict(d=512,  heads=8,  enc=6,  dec=6,  n_mels=80,  n_vocab=51865),
