@@ -56,9 +56,9 @@ def _segs(st):
 def _same(a, b, exact_probs=True):
     assert len(a) == len(b), (len(a), len(b))
     for x, y in zip(a, b):
-        assert (x["t0"], x["t1"], x["ids"], x["tids"], x["text"]) == (y["t0"], y["t1"], y["ids"], y["tids"], y["text"])
-        if exact_probs:
-            assert x["p"] == y["p"] and x["plog"] == y["plog"]
+        assert (x["t0"], x["t1"], x["ids"], x["text"]) == (y["t0"], y["t1"], y["ids"], y["text"])
+        if exact_probs:     # reference-order path: also the per-token probabilities and the argmax-timestamp ids, bit for bit
+            assert x["tids"] == y["tids"] and x["p"] == y["p"] and x["plog"] == y["plog"]
 
 
 @pytest.fixture(scope="module", params=["s128", "s192"])
