@@ -92,8 +92,10 @@ static void linear(hipStream_t s, bool exact, wa_epi_mode mode, const wa_f16 * A
 
 // Pure launch sequence of one decoder pass (no host synchronisation, no KV metadata): tokens/positions/
 // rows/mask are already in d_tok/d_pos/d_rows/d_mask.  `mask` may be null (every cell < n_kv visible).
+// `dyn`: device {n_kv, kv_head}; when non-null the kernels read both from there (the captured graph is replayed with
+// different values every token) and the scalar arguments are ignored.
 static void decode_launch(whisper_context & ctx, whisper_state & st, int n_tokens, int n_kv, int kv_head, const int8_t * mask, int n_rows,
-                          bool save_aheads) {
+                          bool save_aheads, const int * dyn = nullptr) {
     const auto & m  = ctx.model;
     const auto & hp = m.hp;
     auto & kv = st.kv_self;
@@ -114,11 +116,11 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
         {   // LayerNorm + fused q|k|v: q scaled -> d_dq ; k scaled, v -> straight into their KV cells [kv_head, kv_head + n_tokens)
             wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
             e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
-            e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
+            e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head; e.dyn = dyn;
             ln_linear(s, ctx.exact, WA_EPI_DEC_QKV, st.d_dx, d, L.attn_ln, hp.eps, st.d_dxn, L.qkv, n_tokens, nullptr, e);
         }
         wa_launch_attn_exact(s, st.d_dq, d, kv.k + il * kv_layer, 64, d, kv.v + il * kv_layer, 64, d, H, n_tokens, n_kv, mask, 1.0f,
-                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr);
+                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr, dyn);
         {
             wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
             linear(s, ctx.exact, WA_EPI_RESID, st.d_dao, d, L.out, n_tokens, e);
@@ -202,7 +204,34 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     if (n_rows) (void) hipMemcpyAsync(st.d_rows, h_rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice, s);
     (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
 
-    decode_launch(ctx, st, n_tokens, n_kv, kv_head, st.d_mask, n_rows, save_aheads);
+    // single token, every cell below n_kv visible (the greedy steady state): replay the captured hipGraph of the pass
+    bool need_mask = false;
+    for (size_t i = 0; i < (size_t) n_tokens * n_kv && !need_mask; ++i) need_mask = h_mask[i] != 0;
+    if (st.graphs_enabled && n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads) {
+        const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx;
+        if (st.dec_graph && (st.dec_graph_T != T || st.dec_graph_kv_size != kv.size || st.dec_graph_kv_k != kv.k)) {
+            (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr;
+        }
+        int32_t * h_dyn = st.h_stage_i32 + 3 * st.dec_mpad;
+        h_dyn[0] = n_kv; h_dyn[1] = kv_head;
+        (void) hipMemcpyAsync(st.d_dyn, h_dyn, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s);
+        if (!st.dec_graph) {
+            hipGraph_t g = nullptr;
+            if (WA_HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
+                decode_launch(ctx, st, 1, n_kv, kv_head, nullptr, 1, false, st.d_dyn);
+                if (WA_HIP_OK(hipStreamEndCapture(s, &g)) && g) {
+                    if (!WA_HIP_OK(hipGraphInstantiate(&st.dec_graph, g, nullptr, nullptr, 0))) st.dec_graph = nullptr;
+                    (void) hipGraphDestroy(g);
+                }
+            }
+            if (st.dec_graph) { st.dec_graph_T = T; st.dec_graph_kv_size = kv.size; st.dec_graph_kv_k = kv.k; }
+            else { st.graphs_enabled = false; WA_WARN("%s: hipGraph capture failed, falling back to eager launches\n", __func__); }
+        }
+        if (st.dec_graph) { if (!WA_HIP_OK(hipGraphLaunch(st.dec_graph, s))) return false; }
+        else decode_launch(ctx, st, n_tokens, n_kv, kv_head, nullptr, n_rows, save_aheads);
+    } else {
+        decode_launch(ctx, st, n_tokens, n_kv, kv_head, need_mask ? st.d_mask : nullptr, n_rows, save_aheads);
+    }
     if (n_rows) (void) hipMemcpyAsync(st.h_logits_pinned, st.d_logits, (size_t) n_rows * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
     for (int r = 0; r < n_rows; ++r)
@@ -235,14 +264,26 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     (void) hipMemcpyAsync(st->d_rows, h + 2, sizeof(int32_t), hipMemcpyHostToDevice, s);
     hipEvent_t e0, e1;
     if (!WA_HIP_OK(hipEventCreate(&e0)) || !WA_HIP_OK(hipEventCreate(&e1))) return -1;
-    decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false);      // warm-up
+    h[3] = n_past + 1; h[4] = n_past;
+    (void) hipMemcpyAsync(st->d_dyn, h + 3, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    hipGraphExec_t ge = nullptr;
+    if (st->graphs_enabled) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false, st->d_dyn);
+            if (hipStreamEndCapture(s, &g) == hipSuccess && g) { if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr; (void) hipGraphDestroy(g); }
+        }
+    }
+    auto one = [&]() { if (ge) (void) hipGraphLaunch(ge, s); else decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false); };
+    one();      // warm-up
     (void) hipEventRecord(e0, s);
-    for (int i = 0; i < n_iters; ++i) decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false);
+    for (int i = 0; i < n_iters; ++i) one();
     (void) hipEventRecord(e1, s);
     if (!WA_HIP_OK(hipEventSynchronize(e1))) return -1;
     float ms = 0.f;
     (void) hipEventElapsedTime(&ms, e0, e1);
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (ge) (void) hipGraphExecDestroy(ge);
     *ms_per_step = ms / n_iters;
     return 0;
 }

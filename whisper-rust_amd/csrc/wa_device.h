@@ -97,9 +97,10 @@ __device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float 
         dst[(((size_t) il * n_head + hd) * e.aux0 + m) * 64 + c] = f2h(v);
     } else if (EPI == WA_EPI_DEC_QKV) {
         if (e.scale) v = v * e.scale[n];
+        const int row_off = e.dyn ? e.dyn[1] : e.row_off;
         if (n < e.split0)      ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
-        else if (n < e.split1) ((wa_f16 *) e.out2)[(size_t) (e.row_off + m) * e.ldo2 + (n - e.split0)] = f2h(v);
-        else                   ((wa_f16 *) e.out3)[(size_t) (e.row_off + m) * e.ldo3 + (n - e.split1)] = f2h(v);
+        else if (n < e.split1) ((wa_f16 *) e.out2)[(size_t) (row_off + m) * e.ldo2 + (n - e.split0)] = f2h(v);
+        else                   ((wa_f16 *) e.out3)[(size_t) (row_off + m) * e.ldo3 + (n - e.split1)] = f2h(v);
     }
 }
 

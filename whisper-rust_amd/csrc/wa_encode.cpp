@@ -8,6 +8,7 @@
 #include "wa_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 template <typename T> static bool dev_alloc(T *& p, size_t n_elem, bool zero = true) {
@@ -21,6 +22,7 @@ template <typename T> static void dev_free(T *& p) { if (p) { (void) hipFree(p);
 
 bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells) {
     const auto & hp = ctx.model.hp;
+    if (st.dec_graph) { (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr; }
     dev_free(st.kv_self.k);
     dev_free(st.kv_self.v);
     st.kv_self.size = n_cells;
@@ -75,6 +77,8 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
     if (!dev_alloc(st.d_dff,  (size_t) mpad * 4 * d)) return false;
     if (!dev_alloc(st.d_dq,   (size_t) mpad * d)) return false;
     if (!dev_alloc(st.d_logits, (size_t) WA_MAX_DECODERS * hp.n_vocab, false)) return false;
+    if (!dev_alloc(st.d_dyn, 8)) return false;
+    { const char * g = getenv("WHISPER_AMD_NO_GRAPH"); st.graphs_enabled = !(g && g[0] == '1'); }
     if (!dev_alloc(st.d_att_partial, (size_t) 512 * 32 * 64) || !dev_alloc(st.d_att_pleft, (size_t) 512 * 32)) return false;
     if (!dev_alloc(st.d_im2col, std::max((size_t) 2 * T * 3 * hp.n_mels, (size_t) T * 3 * d) + 64)) return false;
     if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_stage_i32, (size_t) 4 * mpad * sizeof(int32_t)))) return false;
@@ -101,7 +105,8 @@ void wa_state_release(whisper_state & st) {
     dev_free(st.kv_self.k); dev_free(st.kv_self.v);
     dev_free(st.d_tok); dev_free(st.d_pos); dev_free(st.d_cell); dev_free(st.d_rows); dev_free(st.d_mask);
     dev_free(st.d_dx); dev_free(st.d_dxn); dev_free(st.d_dqkv); dev_free(st.d_dao); dev_free(st.d_dff); dev_free(st.d_dq);
-    dev_free(st.d_att_partial); dev_free(st.d_att_pleft); dev_free(st.d_im2col); dev_free(st.d_logits); dev_free(st.d_aheads_qk);
+    if (st.dec_graph) { (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr; }
+    dev_free(st.d_dyn); dev_free(st.d_att_partial); dev_free(st.d_att_pleft); dev_free(st.d_im2col); dev_free(st.d_logits); dev_free(st.d_aheads_qk);
     if (st.h_stage_i32)     { (void) hipHostFree(st.h_stage_i32);     st.h_stage_i32 = nullptr; }
     if (st.h_stage_mask)    { (void) hipHostFree(st.h_stage_mask);    st.h_stage_mask = nullptr; }
     if (st.h_logits_pinned) { (void) hipHostFree(st.h_logits_pinned); st.h_logits_pinned = nullptr; }

@@ -350,9 +350,11 @@ void wa_launch_im2col3(hipStream_t s, const wa_f16 * src, int src_ld, int row0, 
 template <int RS>
 __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
                                                             int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
-                                                            int n_kv, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
-                                                            wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out) {
+                                                            int n_kv_arg, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
+                                                            wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out,
+                                                            const int * __restrict__ dyn) {
     constexpr int NW = ATT_THREADS / 64;
+    const int n_kv = dyn ? dyn[0] : n_kv_arg;
     __shared__ float sc[ATT_MAXKV];
     __shared__ wa_f16 p16[ATT_MAXKV];
     __shared__ float gs[ATT_MAXKV / 8];
@@ -503,9 +505,10 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
 }
 
 __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ partial, const wa_f16 * __restrict__ p_left,
-                                                     const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride, int n_kv,
-                                                     wa_f16 * __restrict__ out, int ldo) {
+                                                     const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride, int n_kv_arg,
+                                                     wa_f16 * __restrict__ out, int ldo, const int * __restrict__ dyn) {
     const int j = blockIdx.x, h = blockIdx.y, n_head = gridDim.y, dh = threadIdx.x;
+    const int n_kv = dyn ? dyn[0] : n_kv_arg;
     const size_t pb = ((size_t) j * n_head + h) * 32;
     float s32[32];
 #pragma unroll
@@ -526,14 +529,14 @@ __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ 
 
 void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
-                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out) {
+                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn) {
     if ((long) n_tokens * n_head >= 512) {
         hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn);
     } else {
         hipLaunchKernelGGL((k_attn_exact<4>), dim3(n_head * 4, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn);
         hipLaunchKernelGGL(k_attn_combine, dim3(n_tokens, n_head), dim3(64), 0, s, partial, p_left, vbase, v_head_stride, v_row_stride, n_kv,
-                           out, ldo);
+                           out, ldo, dyn);
     }
 }

@@ -24,16 +24,32 @@ const char * const k_non_speech[] = {   // whisper.cpp:6102-6107
     "♪♪♪", "♩", "♪", "♫", "♬", "♭", "♮", "♯",
 };
 
-// log-softmax / softmax over the filtered logits (whisper.cpp:6109-6143): sequential F32 sums
+// log-softmax / softmax over the filtered logits (whisper.cpp:6109-6143).  The reference forms
+//     lse = logf( sum_i expf(logits[i] - max) ) + max
+// as a sequential F32 sum in index order with libm expf.  The same value is produced here without evaluating
+// expf for terms that provably cannot change the running sum: in round-to-nearest S + t == S whenever
+// t < ulp(S)/2, and ulp(S)/2 >= 2^-25 S, so every term with  logits[i] - max < ln(S) - 17.5  (2^-25 = e^-17.33;
+// the 0.17 margin covers the <= 1 ulp errors of expf/logf) is skipped - for a peaked distribution that is almost
+// all of the vocabulary.  The terms that matter go through the same libm calls in the same order.
 // `n_max` elements are scanned for the maximum: the reference takes it over the WHOLE vector it is handed, which
 // for the no-speech probe is every row of the prompt's logits buffer, not just the n it normalises (whisper.cpp:6113).
-void compute_logprobs(const float * logits, int n, float * logprobs, size_t n_max = 0) {
+float logsumexp_ref_order(const float * logits, int n, size_t n_max = 0) {
     float mx = logits[0];
     const size_t nm = n_max > (size_t) n ? n_max : (size_t) n;
     for (size_t i = 1; i < nm; ++i) if (logits[i] > mx) mx = logits[i];
-    float lse = 0.0f;
-    for (int i = 0; i < n; ++i) if (logits[i] > -INFINITY) lse += expf(logits[i] - mx);
-    lse = logf(lse) + mx;
+    float S = 0.0f;
+    float thr = -INFINITY;                  // terms with (logits[i] - mx) < thr leave S unchanged
+    for (int i = 0; i < n; ++i) {
+        const float d = logits[i] - mx;
+        if (!(d >= thr) || !(logits[i] > -INFINITY)) continue;
+        const float S0 = S;
+        S += expf(d);
+        if (S != S0) thr = logf(S) - 17.5f;
+    }
+    return logf(S) + mx;
+}
+void compute_logprobs(const float * logits, int n, float * logprobs, size_t n_max = 0) {
+    const float lse = logsumexp_ref_order(logits, n, n_max);
     for (int i = 0; i < n; ++i) logprobs[i] = logits[i] > -INFINITY ? logits[i] - lse : -INFINITY;
 }
 void compute_probs(const float * logits, int n, const float * logprobs, float * probs) {
@@ -77,7 +93,9 @@ struct runner {
     }
 
     // ---- whisper_process_logits (whisper.cpp:6149-6417) ----
-    void process_logits(wa_decoder & dec, float temperature) {
+    // `full_probs`: the samplers that draw from the distribution need every probs[i]; the greedy arg-max needs only
+    // the timestamp range and the candidates around the maximum (sample_token_best), so the 51865 expf calls are skipped.
+    void process_logits(wa_decoder & dec, float temperature, bool full_probs) {
         const auto & cur = dec.sequence.tokens;
         const bool is_initial = cur.empty();
         const int n = n_vocab;
@@ -131,7 +149,8 @@ struct runner {
             for (int i = 1; i < vocab.token_beg; ++i) if (logprobs[i] > max_text) max_text = logprobs[i];
             if (ts_logprob > max_text) for (int i = 0; i < vocab.token_beg; ++i) { logits[i] = -INFINITY; logprobs[i] = -INFINITY; }
         }
-        compute_probs(logits, n, logprobs, dec.probs.data());
+        if (full_probs) compute_probs(logits, n, logprobs, dec.probs.data());
+        else compute_probs(logits + vocab.token_beg, n - vocab.token_beg, logprobs + vocab.token_beg, dec.probs.data() + vocab.token_beg);
     }
 
     // timestamp statistics shared by both samplers (whisper.cpp:6447-6465 / 6529-6547)
@@ -152,7 +171,17 @@ struct runner {
         whisper_token_data r = { 0, 0, 0.0f, 0.0f, 0.0f, 0.0f, -1, -1, -1, 0.0f };
         ts_stats(dec, r.tid, r.pt, r.ptsum, 0);
         if (best) {
-            for (int i = 0; i < n_vocab; ++i) if (r.p < dec.probs[i]) { r.id = i; r.p = dec.probs[i]; r.plog = dec.logprobs[i]; }
+            // reference: first i maximising probs[i] = expf(logprobs[i]) (strict <, whisper.cpp:6468-6474).  expf is
+            // monotonic, so the maximum is expf(max logprob); only entries within 1e-5 of it can round to the same
+            // probability, and only those are exponentiated.
+            float lmax = -INFINITY;
+            for (int i = 0; i < n_vocab; ++i) if (dec.logprobs[i] > lmax) lmax = dec.logprobs[i];
+            if (lmax > -INFINITY) {
+                const float pmax = expf(lmax);
+                for (int i = 0; i < n_vocab; ++i)
+                    if (dec.logprobs[i] >= lmax - 1e-5f && expf(dec.logprobs[i]) == pmax) { r.id = i; r.p = pmax; r.plog = dec.logprobs[i]; break; }
+                if (!(r.p > 0.0f)) { r.id = 0; r.p = 0.0f; r.plog = 0.0f; }     // all-zero probabilities: the reference keeps its initial {0, 0, 0}
+            }
         } else {
             std::discrete_distribution<> dist(dec.probs.begin(), dec.probs.end());
             r.id = dist(dec.rng);
@@ -308,6 +337,8 @@ int runner::run(const float * samples, int n_samples) {
             else if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) n_dec = t_cur > 0.0f ? p.greedy.best_of : p.beam_search.beam_size;
             n_dec = std::max(1, n_dec);
 
+            // greedy arg-max (t == 0) never draws from the distribution: it does not need all 51865 probabilities
+            const bool need_full_probs = p.strategy == WHISPER_SAMPLING_BEAM_SEARCH || !(t_cur < 1e-6f);
             for (int j = 0; j < n_dec; ++j) {      // whisper.cpp:7047-7069
                 auto & dec = st->decoders[j];
                 dec.sequence.tokens.clear();
@@ -350,7 +381,7 @@ int runner::run(const float * samples, int n_samples) {
                 }
                 const int64_t ts = wa_time_us();
                 st->decoders[0].i_batch = (int) prompt.size() - 1;
-                process_logits(st->decoders[0], t_cur);
+                process_logits(st->decoders[0], t_cur, need_full_probs);
                 for (int j = 1; j < n_dec; ++j) {
                     auto & dec = st->decoders[j];
                     wa_kv_seq_cp(st->kv_self, 0, j, -1, -1);
@@ -465,7 +496,7 @@ int runner::run(const float * samples, int n_samples) {
                     for (int j = 0; j < n_dec; ++j) {
                         auto & dec = st->decoders[j];
                         if (dec.failed || dec.completed) continue;
-                        process_logits(dec, t_cur);
+                        process_logits(dec, t_cur, need_full_probs);
                     }
                     st->t_sample_us += wa_time_us() - ts1;
                 }

@@ -220,6 +220,12 @@ struct whisper_state {
     int32_t * d_rows = nullptr;   // [mpad] row indices that need logits
     float  * d_aheads_qk = nullptr; // DTW capture
 
+    // hipGraph of the single-token decoder pass (launch-bound inner loop); parameters that change per token live in d_dyn
+    int32_t * d_dyn = nullptr;            // {n_kv, kv_head}
+    hipGraphExec_t dec_graph = nullptr;
+    int dec_graph_T = 0; uint32_t dec_graph_kv_size = 0; const void * dec_graph_kv_k = nullptr;
+    bool graphs_enabled = true;
+
     // pinned host staging
     int32_t * h_stage_i32 = nullptr; int8_t * h_stage_mask = nullptr; size_t h_mask_cap = 0;
     float * h_logits_pinned = nullptr; size_t h_logits_cap = 0;

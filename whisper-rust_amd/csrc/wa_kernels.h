@@ -33,6 +33,7 @@ struct wa_epi {
     int split0 = 0, split1 = 0;
     int row_off = 0;
     int aux0 = 0, aux1 = 0;
+    const int * dyn = nullptr;   // device {n_kv, kv_head}: when set, row_off is read from dyn[1] (graph-replayed decode step)
 };
 
 // C[M x N] = A[M x K] (f16, row stride lda) * W[N x K]^T (f16, row stride ldw); K % 32 == 0.
@@ -95,4 +96,4 @@ void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int
 // partial: f32 [n_tokens][n_head][32][64], p_left: f16 [n_tokens][n_head][32] (used when n_tokens*n_head < 512).
 void wa_launch_attn_exact(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
-                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out);
+                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn_n_kv = nullptr);
