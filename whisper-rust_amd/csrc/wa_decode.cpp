@@ -287,3 +287,19 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     *ms_per_step = ms / n_iters;
     return 0;
 }
+
+#ifdef WA_STAMP
+#include "wa_kernels.h"
+// temporary instrumentation entry: runs LN+GEMV (cross-q shape) and plain GEMV (out-proj shape) once with stamps
+extern "C" __attribute__((visibility("default"))) void whisper_amd_stamp_probe(struct whisper_context * ctx, struct whisper_state * st, unsigned long long * out) {
+    const auto & m = ctx->model; const int d = m.hp.n_text_state;
+    unsigned long long * dbg = nullptr; (void) hipMalloc((void **) &dbg, 256); (void) hipMemset(dbg, 0, 256);
+    const auto & L = m.dec[0];
+    { wa_epi e; e.bias = L.cross_q.b; e.out = st->d_dq; e.ldo = d; e.dbg = (float *) dbg;
+      wa_launch_ln_gemv_exact(st->stream, WA_EPI_F16, st->d_dx, d, nullptr, L.cross_ln.w, L.cross_ln.b, m.hp.eps, L.cross_q.w, d, 1, d, d, e); }
+    { wa_epi e; e.bias = L.out.b; e.out = st->d_dx; e.ldo = d; e.resid = st->d_dx; e.ldr = d; e.dbg = (float *) (dbg + 16);
+      wa_launch_gemv_exact(st->stream, WA_EPI_RESID, st->d_dao, d, nullptr, L.out.w, d, 1, d, d, e); }
+    (void) hipStreamSynchronize(st->stream);
+    (void) hipMemcpy(out, dbg, 256, hipMemcpyDeviceToHost); (void) hipFree(dbg);
+}
+#endif

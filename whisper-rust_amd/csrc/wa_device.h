@@ -22,10 +22,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
+// DPP cross-lane moves (one VALU op each; ds_bpermute-based __shfl costs a ~100-cycle LDS crossbar trip, which is
+// what the latency-bound decode kernels were spending their time on).  ctrl: row_shl:n = 0x100+n, row_shr:n = 0x110+n,
+// row_bcast15 = 0x142, row_bcast31 = 0x143, quad_perm = 0x00..0xff.  Out-of-range source lanes read 0 (bound_ctrl).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xffffffffll), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned int) lo);
+}
+// wave-wide F64 sum, result broadcast to every lane (order of the additions is arbitrary: callers certify it)
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    v += dpp_f64<0x111>(v);          // row_shr:1
+    v += dpp_f64<0x112>(v);          // row_shr:2
+    v += dpp_f64<0x114>(v);          // row_shr:4
+    v += dpp_f64<0x118>(v);          // row_shr:8  -> lane 15 of each row holds the row total
+    v += dpp_f64<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int) (b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int) (b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned int) lo);
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -66,12 +87,25 @@ __device__ __forceinline__ float wa_gelu(float x, const wa_f16 * __restrict__ ta
 // =================================================================================================
 // GEMM epilogues (shared by the MFMA GEMM and the GEMV)
 // =================================================================================================
+// Operands an epilogue reads besides the accumulator; loading them early (before the K loop) takes their HBM/L2
+// round trip off the critical path of the latency-bound decode kernels.
+struct wa_epi_pre { float bias = 0.f, scale = 1.f, resid = 0.f; };
+
 template <int EPI>
-__device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float acc) {
+__device__ __forceinline__ wa_epi_pre epi_preload(const wa_epi & e, int m, int n) {
+    wa_epi_pre p;
+    if (e.bias) p.bias = e.bias[n];
+    if ((EPI == WA_EPI_F16 || EPI == WA_EPI_CROSS_KV || EPI == WA_EPI_DEC_QKV) && e.scale) p.scale = e.scale[n];
+    if (EPI == WA_EPI_RESID || EPI == WA_EPI_CONV2) p.resid = e.resid[(size_t) m * e.ldr + n];
+    return p;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_apply(const wa_epi & e, int m, int n, float acc, const wa_epi_pre & p) {
     float v = acc;
-    if (EPI != WA_EPI_F32 || e.bias) { if (e.bias) v = v + e.bias[n]; }
+    if (e.bias) v = v + p.bias;
     if (EPI == WA_EPI_F16) {
-        if (e.scale) v = v * e.scale[n];
+        if (e.scale) v = v * p.scale;
         ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
     } else if (EPI == WA_EPI_ENC_QKV) {
         if (n < e.split0) ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
@@ -79,16 +113,16 @@ __device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float 
     } else if (EPI == WA_EPI_GELU_F16) {
         ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(wa_gelu(v, e.gelu));
     } else if (EPI == WA_EPI_RESID) {
-        ((float *) e.out)[(size_t) m * e.ldo + n] = v + e.resid[(size_t) m * e.ldr + n];
+        ((float *) e.out)[(size_t) m * e.ldo + n] = v + p.resid;
     } else if (EPI == WA_EPI_CONV2) {
         const float g = wa_gelu(v, e.gelu);
         if (e.dbg) e.dbg[(size_t) m * e.ldo + n] = g;
-        ((float *) e.out)[(size_t) m * e.ldo + n] = e.resid[(size_t) m * e.ldr + n] + g;
+        ((float *) e.out)[(size_t) m * e.ldo + n] = p.resid + g;
     } else if (EPI == WA_EPI_F32) {
         ((float *) e.out)[(size_t) m * e.ldo + n] = v;
     } else if (EPI == WA_EPI_CROSS_KV) {
         // n = layer*2d + kv*d + head*64 + c ; aux0 = tpad, aux1 = d
-        if (e.scale) v = v * e.scale[n];
+        if (e.scale) v = v * p.scale;
         const int d = e.aux1, two_d = 2 * d;
         const int il = n / two_d, r = n - il * two_d;
         const int kv = r >= d, rr = kv ? r - d : r;
@@ -96,7 +130,7 @@ __device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float 
         wa_f16 * dst = (wa_f16 *) (kv ? e.out2 : e.out);
         dst[(((size_t) il * n_head + hd) * e.aux0 + m) * 64 + c] = f2h(v);
     } else if (EPI == WA_EPI_DEC_QKV) {
-        if (e.scale) v = v * e.scale[n];
+        if (e.scale) v = v * p.scale;
         const int row_off = e.dyn ? e.dyn[1] : e.row_off;
         if (n < e.split0)      ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
         else if (n < e.split1) ((wa_f16 *) e.out2)[(size_t) (row_off + m) * e.ldo2 + (n - e.split0)] = f2h(v);
@@ -104,6 +138,10 @@ __device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float 
     }
 }
 
+template <int EPI>
+__device__ __forceinline__ void epi_store(const wa_epi & e, int m, int n, float acc) {
+    epi_apply<EPI>(e, m, n, acc, epi_preload<EPI>(e, m, n));
+}
 
 // -------------------------------------------------------------------------------------------------
 // reference-order helpers (wa_exact.hip)

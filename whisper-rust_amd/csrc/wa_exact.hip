@@ -119,8 +119,12 @@ void wa_launch_gemm_exact(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int
 // monotonic, so when (S - delta)/n and (S + delta)/n round to the SAME float, that float is the reference's
 // value whatever its order was.  Otherwise (probability ~ n 2^-27 per row) one lane redoes the sum in index order.
 __device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out) {
-    const double delta = 2.0 * (double) n * 0x1p-53 * A * 1.000001;
-    const float lo = (float) ((S - delta) / (double) n), hi = (float) ((S + delta) / (double) n);
+    // conservative bounds of (S -+ delta)/n by multiplication (1/n in F64 is within 2^-53; the 2^-48 slack covers it):
+    // if both bounds round to the same float, the correctly rounded quotient of any sum in the interval does too.
+    const double rn = 1.0 / (double) n;
+    const double delta = (2.0 * (double) n * 0x1p-53 * A + fabs(S) * 0x1p-48) * rn * 1.000001;
+    const double q = S * rn;
+    const float lo = (float) (q - delta), hi = (float) (q + delta);
     out = lo;
     return lo == hi;
 }
@@ -191,37 +195,102 @@ void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int
 struct wa_ln_in { const float * x = nullptr; int ldx = 0; const float * w = nullptr; const float * b = nullptr; float eps = 0.f; };
 
 #define GEMV_BATCH 24      // weight loads kept in flight per lane (8 B each)
+#define GEMV_THREADS 256   // 4 waves = 32 weight rows per block iteration
+#define GEMV_LN_NPL 8      // LayerNorm elements per thread (K <= 2048)
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+// Block-wide LayerNorm of one F32 row (reference-order semantics, certified F64 sums), written as F16 into `dst`.
+// All 256 threads share the row, so each touches K/256 elements: the prologue is issue-bound, not bandwidth-bound.
+__device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr, int K, const wa_ln_in & ln, wa_f16 * __restrict__ dst,
+                                                   double * __restrict__ red /*[16] shared*/, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    float xv[GEMV_LN_NPL], gw[GEMV_LN_NPL], gb[GEMV_LN_NPL];
+#pragma unroll
+    for (int k = 0; k < GEMV_LN_NPL; ++k) {
+        const int i = tid + GEMV_THREADS * k;
+        const bool ok = i < K;
+        xv[k] = ok ? xr[i] : 0.0f; gw[k] = ok ? ln.w[i] : 0.0f; gb[k] = ok ? ln.b[i] : 0.0f;
+    }
+    double s = 0.0, a = 0.0;
+#pragma unroll
+    for (int k = 0; k < GEMV_LN_NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
+    s = wave_sum_d(s); a = wave_sum_d(a);
+    if (lane == 0) { red[wave] = s; red[4 + wave] = a; }
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    a = (red[4] + red[5]) + (red[6] + red[7]);
+    float mean;
+    if (!wa_sum_certain(s, a, K, mean)) {          // block-uniform decision
+        if (tid == 0) { double t = 0.0; for (int i = 0; i < K; ++i) t += (double) xr[i]; red[8] = t; }
+        __syncthreads();
+        mean = (float) (red[8] / (double) K);
+    }
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < GEMV_LN_NPL; ++k) if (tid + GEMV_THREADS * k < K) { const float v = xv[k] - mean; s2 += (double) (v * v); }
+    s2 = wave_sum_d(s2);
+    if (lane == 0) red[12 + wave] = s2;
+    __syncthreads();
+    s2 = (red[12] + red[13]) + (red[14] + red[15]);
+    float variance;
+    if (!wa_sum_certain(s2, s2, K, variance)) {
+        if (tid == 0) { double t = 0.0; for (int i = 0; i < K; ++i) { const float v = xr[i] - mean; t += (double) (v * v); } red[9] = t; }
+        __syncthreads();
+        variance = (float) (red[9] / (double) K);
+    }
+    const float scale = 1.0f / sqrtf(variance + ln.eps);
+#pragma unroll
+    for (int k = 0; k < GEMV_LN_NPL; ++k) {
+        const int i = tid + GEMV_THREADS * k;
+        if (i < K) {
+            float y = xv[k] - mean;
+            y = y * scale;
+            y = y * gw[k];
+            y = y + gb[k];
+            dst[i] = f2h(y);
+        }
+    }
+    __syncthreads();       // `red` is reused by the next row
+}
 
 template <int MT, int EPI>
-__global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ A, int lda, const int32_t * __restrict__ rows, wa_ln_in ln,
-                                                    const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
+__global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __restrict__ A, int lda, const int32_t * __restrict__ rows, wa_ln_in ln,
+                                                             const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
     extern __shared__ __attribute__((aligned(16))) wa_f16 xs[];   // [MT][K]
+    __shared__ double red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane & 7, slot = lane >> 3;
+    const int nsteps = K >> 5;
+
+    // The weights do not depend on the previous kernel's output: issue the first batch of loads BEFORE staging the
+    // activations, so the HBM round trip overlaps the LayerNorm / copy prologue instead of following it.
+    half4v wv[GEMV_BATCH];
+    auto load_batch = [&](const wa_f16 * wrow, int s0) {
+#pragma unroll
+        for (int b = 0; b < GEMV_BATCH; ++b) {
+            const int s = s0 + b < nsteps ? s0 + b : nsteps - 1;
+            wv[b] = *(const half4v *) (wrow + s * 32);
+        }
+    };
+    {
+        const int n = blockIdx.x * 32 + wave * 8 + slot;
+        const int nn = n < N ? n : N - 1;
+        load_batch(W + (size_t) nn * ldw + 4 * u, 0);
+    }
+
     if (ln.x) {
-        for (int m = wave; m < MT; m += 2) {
+        for (int m = 0; m < MT; ++m) {
             if (m < M) {
                 const int src = rows ? rows[m] : m;
-                const float * xr = ln.x + (size_t) src * ln.ldx;
-                float xv[LN_NPL], mean, scale;
-                wa_ln_stats(xr, K, ln.eps, lane, xv, mean, scale);
-#pragma unroll
-                for (int k = 0; k < LN_NPL; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < K) {
-                        float y = xv[k] - mean;
-                        y = y * scale;
-                        y = y * ln.w[i];
-                        y = y + ln.b[i];
-                        xs[(size_t) m * K + i] = f2h(y);
-                    }
-                }
+                wa_block_layernorm(ln.x + (size_t) src * ln.ldx, K, ln, xs + (size_t) m * K, red, tid);
             } else {
-                for (int i = lane; i < K; i += 64) xs[(size_t) m * K + i] = 0;
+                for (int i = tid; i < K; i += GEMV_THREADS) xs[(size_t) m * K + i] = 0;
             }
         }
     } else {
         const int kc = K >> 3;
-        for (int c = tid; c < MT * kc; c += 128) {
+        for (int c = tid; c < MT * kc; c += GEMV_THREADS) {
             const int m = c / kc, cc = c - m * kc;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (m < M) { const int src = rows ? rows[m] : m; v = *(const uint4 *) (A + (size_t) src * lda + cc * 8); }
@@ -229,53 +298,53 @@ __global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ 
         }
     }
     __syncthreads();
-    const int u = lane & 7, slot = lane >> 3;
-    const int nsteps = K >> 5;
-    for (int nb = blockIdx.x * 16; nb < N; nb += gridDim.x * 16) {
+    bool first = true;
+    for (int nb = blockIdx.x * 32; nb < N; nb += gridDim.x * 32) {
         const int n = nb + wave * 8 + slot;
         const int nn = n < N ? n : N - 1;
         const wa_f16 * wrow = W + (size_t) nn * ldw + 4 * u;
         float acc[MT][4];
+        wa_epi_pre pre[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[m][i] = 0.0f;
-        for (int s0 = 0; s0 < nsteps; s0 += GEMV_BATCH) {
-            uint2 wv[GEMV_BATCH];
+            if (u == 0 && m < M) pre[m] = epi_preload<EPI>(e, m, nn);    // bias / scale / residual: fetched under the K loop
+        }
+        auto fma_step = [&](int b, int sidx) {     // (float) of a packed half feeds v_fma_mix_f32 directly: 4 VALU ops per step and token
+            const half4v w4 = wv[b];
 #pragma unroll
-            for (int b = 0; b < GEMV_BATCH; ++b) {
-                const int s = s0 + b < nsteps ? s0 + b : nsteps - 1;
-                wv[b] = *(const uint2 *) (wrow + s * 32);
+            for (int m = 0; m < MT; ++m) {
+                const half4v x4 = *(const half4v *) (&xs[(size_t) m * K + sidx * 32 + 4 * u]);
+                acc[m][0] = fmaf((float) w4[0], (float) x4[0], acc[m][0]);
+                acc[m][1] = fmaf((float) w4[1], (float) x4[1], acc[m][1]);
+                acc[m][2] = fmaf((float) w4[2], (float) x4[2], acc[m][2]);
+                acc[m][3] = fmaf((float) w4[3], (float) x4[3], acc[m][3]);
             }
+        };
+        for (int s0 = 0; s0 < nsteps; s0 += GEMV_BATCH) {
+            if (!(first && s0 == 0)) load_batch(wrow, s0);
+            if (s0 + GEMV_BATCH <= nsteps) {          // full batch: straight-line code, the LDS reads pipeline freely
 #pragma unroll
-            for (int b = 0; b < GEMV_BATCH; ++b) {
-                if (s0 + b < nsteps) {
-                    const wa_f16 * w4 = (const wa_f16 *) &wv[b];
-                    const float w0 = h2f(w4[0]), w1 = h2f(w4[1]), w2 = h2f(w4[2]), w3 = h2f(w4[3]);
+                for (int b = 0; b < GEMV_BATCH; ++b) fma_step(b, s0 + b);
+            } else {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const uint2 xv = *(const uint2 *) (&xs[(size_t) m * K + (s0 + b) * 32 + 4 * u]);
-                        const wa_f16 * x4 = (const wa_f16 *) &xv;
-                        acc[m][0] = fmaf(w0, h2f(x4[0]), acc[m][0]);
-                        acc[m][1] = fmaf(w1, h2f(x4[1]), acc[m][1]);
-                        acc[m][2] = fmaf(w2, h2f(x4[2]), acc[m][2]);
-                        acc[m][3] = fmaf(w3, h2f(x4[3]), acc[m][3]);
-                    }
-                }
+                for (int b = 0; b < GEMV_BATCH; ++b) if (s0 + b < nsteps) fma_step(b, s0 + b);
             }
         }
+        first = false;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float t[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i) {         // directed: the result is complete in lane u == 0 of each 8-lane group
                 float v = acc[m][i];
-                v = v + __shfl_xor(v, 4, WAVE);     // s[j] + s[j+2]
-                v = v + __shfl_xor(v, 2, WAVE);     // (s0+s2) + (s1+s3)
-                t[i] = v + __shfl_xor(v, 1, WAVE);  // a[l] + a[l+4]
+                v = v + dpp_f32<0x104>(v);          // row_shl:4  s[j] + s[j+2]
+                v = v + dpp_f32<0x102>(v);          // row_shl:2  (s0+s2) + (s1+s3)
+                t[i] = v + dpp_f32<0x101>(v);       // row_shl:1  a[l] + a[l+4]
             }
             const float res = (t[0] + t[1]) + (t[2] + t[3]);
-            if (u == 0 && n < N && m < M) epi_store<EPI>(e, m, n, res);
+            if (u == 0 && n < N && m < M) epi_apply<EPI>(e, m, n, res, pre[m]);
         }
     }
 }
@@ -283,12 +352,12 @@ __global__ __launch_bounds__(128) void k_gemv_exact(const wa_f16 * __restrict__ 
 template <int MT>
 static void gemv_exact_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_ln_in & ln,
                                 const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
-    int grid = (N + 15) / 16;
+    int grid = (N + 31) / 32;
     if (grid > 4096) grid = 4096;
     const size_t lds = (size_t) MT * K * sizeof(wa_f16);
 #define WA_CASE(E) case E: { \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_gemv_exact<MT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL((k_gemv_exact<MT, E>), dim3(grid), dim3(128), lds, s, A, lda, rows, ln, W, ldw, M, N, K, e); } break;
+        hipLaunchKernelGGL((k_gemv_exact<MT, E>), dim3(grid), dim3(GEMV_THREADS), lds, s, A, lda, rows, ln, W, ldw, M, N, K, e); } break;
     switch (mode) {
         WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_GELU_F16) WA_CASE(WA_EPI_RESID) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_DEC_QKV)
         default: break;
@@ -399,8 +468,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
                 for (int l = 0; l < 8; ++l) {
                     float t = fmaf(h2f(k8a[l]), qa[l], 0.0f);
                     t = fmaf(h2f(k8b[l]), qb[l], t);
-                    t = t + __shfl_xor(t, 2, WAVE);          // s[j] + s[j+2]
-                    v[l] = t + __shfl_xor(t, 1, WAVE);       // (s0+s2) + (s1+s3)
+                    t = t + dpp_f32<0x4e>(t);                // quad_perm [2,3,0,1]: s[j] + s[j+2]
+                    v[l] = t + dpp_f32<0xb1>(t);             // quad_perm [1,0,3,2]: (s0+s2) + (s1+s3)
                 }
                 const float t0 = v[0] + v[4], t1 = v[1] + v[5], t2 = v[2] + v[6], t3 = v[3] + v[7];
                 float r = ((t0 + t1) + (t2 + t3)) * scale;
