@@ -13,6 +13,7 @@
 //                  one lane in index order.
 // Compiled with -ffp-contract=off: fmaf is the only fused operation.
 #include "wa_device.h"
+#include <cstdlib>
 
 // =================================================================================================
 // GEMM (any M): C = A W^T in ggml_vec_dot_f16 order.  VALU, not MFMA: the MFMA's internal summation
@@ -599,7 +600,10 @@ __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ 
 void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
                           float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn) {
-    if ((long) n_tokens * n_head >= 512) {
+    // few (token, head) pairs and a long key range (decode cross-attention): spread the 32 partial-sum chains over 4 blocks
+    // per pair and finish in k_attn_combine; otherwise one block per pair finishes in LDS (encoder, prompt, self-attention)
+    const bool split = (long) n_tokens * n_head < 512 && n_kv > 512;
+    if (!split) {
         hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
                            v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn);
     } else {
