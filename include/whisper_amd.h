@@ -465,9 +465,9 @@ WHISPER_API int whisper_amd_decoder_info(struct whisper_state * state, int j, do
  * Needs a prior whisper_encode*; touches KV cell `n_past` of the state.  0 on success. */
 WHISPER_API int whisper_amd_decode_step_probe(struct whisper_context * ctx, struct whisper_state * state, int n_past, int n_iters, float * ms_per_step);
 
-/* Batched chunk-parallel transcription on ONE device: runs `n_chunks` independent
- * whisper_full_with_state jobs, each on its own state, decoding them in lock-step so that one
- * pass over the decoder weights serves all live chunks.  samples[i] may be host or device pointers.
+/* Chunk-parallel transcription on ONE device: runs `n_chunks` independent whisper_full_with_state
+ * jobs concurrently, each on its own state / HIP stream / host thread (the single-stream decode step is latency-bound
+ * and fills a fraction of the chip, so the streams overlap).  samples[i] may be host or device pointers.
  * Returns 0 or the first non-zero per-chunk code. */
 WHISPER_API int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state ** states, int n_chunks,
                                        struct whisper_full_params params, const float * const * samples, const int * n_samples);

@@ -151,6 +151,9 @@ whisper_context * init_common(whisper_model_loader * loader, whisper_context_par
         loader->close(loader->context);
         return nullptr;
     }
+    // spin-wait synchronisation: the decode loop synchronises once per token, an interrupt wake-up costs tens of microseconds
+    (void) hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void) hipGetLastError();
     whisper_context * ctx = new whisper_context;
     ctx->params = params;
     ctx->device = params.gpu_device;
@@ -682,13 +685,18 @@ int whisper_amd_decoder_info(struct whisper_state * st, int j, double out[8], in
 
 int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state ** states, int n_chunks, struct whisper_full_params params,
                            const float * const * samples, const int * n_samples) {
-    // v1: sequential over the chunks' own states (lock-step batched decode is the planned form)
-    int rc = 0;
-    for (int i = 0; i < n_chunks; ++i) {
-        const int r = whisper_full_with_state(ctx, states[i], params, samples[i], n_samples[i]);
-        if (r != 0 && rc == 0) rc = r;
-    }
-    return rc;
+    // Chunks are independent: each runs the ordinary whisper_full_with_state loop on its own state and HIP
+    // stream from its own host thread.  A single decode step is latency-bound and occupies a fraction of the 256 CUs, so the
+    // streams overlap on the device; the weights are shared and read-only.  Callbacks, if any, fire concurrently.
+    if (!ctx || !states || n_chunks <= 0) return -1;
+    std::vector<int> rc(n_chunks, 0);
+    std::vector<std::thread> th;
+    th.reserve(n_chunks);
+    for (int i = 0; i < n_chunks; ++i)
+        th.emplace_back([&, i]() { rc[i] = whisper_full_with_state(ctx, states[i], params, samples[i], n_samples[i]); });
+    for (auto & t : th) t.join();
+    for (int r : rc) if (r != 0) return r;
+    return 0;
 }
 
 } // extern "C"

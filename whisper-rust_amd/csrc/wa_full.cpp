@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <regex>
+#include <immintrin.h>
 
 void wa_dtw_timestamps(whisper_context * ctx, whisper_state * st, const whisper_full_params & params, int i_segment, size_t n_segments,
                        int seek, int n_frames, int medfilt_width);   // wa_dtw.cpp
@@ -33,24 +34,54 @@ const char * const k_non_speech[] = {   // whisper.cpp:6102-6107
 // all of the vocabulary.  The terms that matter go through the same libm calls in the same order.
 // `n_max` elements are scanned for the maximum: the reference takes it over the WHOLE vector it is handed, which
 // for the no-speech probe is every row of the prompt's logits buffer, not just the n it normalises (whisper.cpp:6113).
+// 8-wide helpers for the 51865-wide passes (host file is built with -mavx2, no FMA contraction)
+inline float max_f32(const float * x, size_t n) {
+    size_t i = 0;
+    float mx = -INFINITY;
+    if (n >= 8) {
+        __m256 m = _mm256_loadu_ps(x);
+        for (i = 8; i + 8 <= n; i += 8) m = _mm256_max_ps(m, _mm256_loadu_ps(x + i));
+        float t[8]; _mm256_storeu_ps(t, m);
+        for (int k = 0; k < 8; ++k) if (t[k] > mx) mx = t[k];
+    }
+    for (; i < n; ++i) if (x[i] > mx) mx = x[i];
+    return mx;
+}
+
 float logsumexp_ref_order(const float * logits, int n, size_t n_max = 0) {
-    float mx = logits[0];
-    const size_t nm = n_max > (size_t) n ? n_max : (size_t) n;
-    for (size_t i = 1; i < nm; ++i) if (logits[i] > mx) mx = logits[i];
+    const float mx = max_f32(logits, n_max > (size_t) n ? n_max : (size_t) n);
     float S = 0.0f;
     float thr = -INFINITY;                  // terms with (logits[i] - mx) < thr leave S unchanged
-    for (int i = 0; i < n; ++i) {
+    auto add = [&](int i) {                 // index order is preserved: candidates of a block are visited in order
         const float d = logits[i] - mx;
-        if (!(d >= thr) || !(logits[i] > -INFINITY)) continue;
+        if (!(d >= thr) || !(logits[i] > -INFINITY)) return;
         const float S0 = S;
         S += expf(d);
         if (S != S0) thr = logf(S) - 17.5f;
+    };
+    int i = 0;
+    const __m256 vmx = _mm256_set1_ps(mx), vninf = _mm256_set1_ps(-INFINITY);
+    for (; i + 8 <= n; i += 8) {
+        const __m256 x = _mm256_loadu_ps(logits + i);
+        const __m256 d = _mm256_sub_ps(x, vmx);
+        // thr only grows, so a lane that fails the test now would also fail it later in this block
+        const __m256 ok = _mm256_and_ps(_mm256_cmp_ps(d, _mm256_set1_ps(thr), _CMP_GE_OQ), _mm256_cmp_ps(x, vninf, _CMP_GT_OQ));
+        int mask = _mm256_movemask_ps(ok);
+        while (mask) { const int k = __builtin_ctz(mask); mask &= mask - 1; add(i + k); }
     }
+    for (; i < n; ++i) add(i);
     return logf(S) + mx;
 }
 void compute_logprobs(const float * logits, int n, float * logprobs, size_t n_max = 0) {
     const float lse = logsumexp_ref_order(logits, n, n_max);
-    for (int i = 0; i < n; ++i) logprobs[i] = logits[i] > -INFINITY ? logits[i] - lse : -INFINITY;
+    int i = 0;
+    const __m256 vl = _mm256_set1_ps(lse), vninf = _mm256_set1_ps(-INFINITY);
+    for (; i + 8 <= n; i += 8) {
+        const __m256 x = _mm256_loadu_ps(logits + i);
+        const __m256 fin = _mm256_cmp_ps(x, vninf, _CMP_GT_OQ);
+        _mm256_storeu_ps(logprobs + i, _mm256_blendv_ps(vninf, _mm256_sub_ps(x, vl), fin));
+    }
+    for (; i < n; ++i) logprobs[i] = logits[i] > -INFINITY ? logits[i] - lse : -INFINITY;
 }
 void compute_probs(const float * logits, int n, const float * logprobs, float * probs) {
     for (int i = 0; i < n; ++i) probs[i] = logits[i] == -INFINITY ? 0.0f : expf(logprobs[i]);
@@ -139,14 +170,12 @@ struct runner {
         {   // if the timestamp mass beats every text token, force a timestamp (whisper.cpp:6309-6333)
             float ts_logprob = -INFINITY;
             {
-                float mx = logprobs[vocab.token_beg];
-                for (int i = vocab.token_beg + 1; i < n; ++i) if (logprobs[i] > mx) mx = logprobs[i];
+                const float mx = max_f32(logprobs + vocab.token_beg, n - vocab.token_beg);
                 float lse = 0.0f;
                 for (int i = vocab.token_beg; i < n; ++i) if (logprobs[i] > -INFINITY) lse += expf(logprobs[i] - mx);
                 if (lse > 0.0f) ts_logprob = logf(lse) + mx;
             }
-            float max_text = logprobs[0];
-            for (int i = 1; i < vocab.token_beg; ++i) if (logprobs[i] > max_text) max_text = logprobs[i];
+            const float max_text = max_f32(logprobs, vocab.token_beg);
             if (ts_logprob > max_text) for (int i = 0; i < vocab.token_beg; ++i) { logits[i] = -INFINITY; logprobs[i] = -INFINITY; }
         }
         if (full_probs) compute_probs(logits, n, logprobs, dec.probs.data());
@@ -174,12 +203,21 @@ struct runner {
             // reference: first i maximising probs[i] = expf(logprobs[i]) (strict <, whisper.cpp:6468-6474).  expf is
             // monotonic, so the maximum is expf(max logprob); only entries within 1e-5 of it can round to the same
             // probability, and only those are exponentiated.
-            float lmax = -INFINITY;
-            for (int i = 0; i < n_vocab; ++i) if (dec.logprobs[i] > lmax) lmax = dec.logprobs[i];
+            const float lmax = max_f32(dec.logprobs.data(), n_vocab);
             if (lmax > -INFINITY) {
                 const float pmax = expf(lmax);
-                for (int i = 0; i < n_vocab; ++i)
-                    if (dec.logprobs[i] >= lmax - 1e-5f && expf(dec.logprobs[i]) == pmax) { r.id = i; r.p = pmax; r.plog = dec.logprobs[i]; break; }
+                const __m256 vth = _mm256_set1_ps(lmax - 1e-5f);
+                int i = 0;
+                bool found = false;
+                for (; i + 8 <= n_vocab && !found; i += 8) {
+                    int mask = _mm256_movemask_ps(_mm256_cmp_ps(_mm256_loadu_ps(dec.logprobs.data() + i), vth, _CMP_GE_OQ));
+                    while (mask) {
+                        const int k = __builtin_ctz(mask); mask &= mask - 1;
+                        if (expf(dec.logprobs[i + k]) == pmax) { r.id = i + k; r.p = pmax; r.plog = dec.logprobs[i + k]; found = true; break; }
+                    }
+                }
+                for (; i < n_vocab && !found; ++i)
+                    if (dec.logprobs[i] >= lmax - 1e-5f && expf(dec.logprobs[i]) == pmax) { r.id = i; r.p = pmax; r.plog = dec.logprobs[i]; found = true; }
                 if (!(r.p > 0.0f)) { r.id = 0; r.p = 0.0f; r.plog = 0.0f; }     // all-zero probabilities: the reference keeps its initial {0, 0, 0}
             }
         } else {

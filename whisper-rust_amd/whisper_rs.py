@@ -206,6 +206,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     proto("whisper_print_timings", None, P)
     proto("whisper_reset_timings", None, P)
     proto("whisper_log_set", None, LOG_CB, P)
+    if hasattr(lib, "whisper_amd_full_batch"):
+        proto("whisper_amd_full_batch", I, P, C.POINTER(C.c_void_p), I, whisper_full_params, C.POINTER(C.c_void_p), C.POINTER(C.c_int))
     _LIBS[path] = lib
     return lib
 
@@ -337,6 +339,24 @@ class WhisperContext:
         if self.ptr:
             self.lib.whisper_free(self.ptr)
             self.ptr = None
+
+
+def full_batch(ctx: "WhisperContext", states: Sequence["WhisperState"], params: "FullParams", pcms: Sequence) -> int:
+    """Extension: transcribe several independent chunks concurrently on one device (whisper_amd_full_batch).
+    `pcms[i]` is a numpy f32 array or a (device_ptr, n) tuple."""
+    n = len(states)
+    keep, ptrs, lens = [], (C.c_void_p * n)(), (C.c_int * n)()
+    for i, p in enumerate(pcms):
+        if isinstance(p, tuple):
+            ptrs[i], lens[i] = p[0], p[1]
+        else:
+            a = np.ascontiguousarray(p, dtype=np.float32); keep.append(a)
+            ptrs[i], lens[i] = a.ctypes.data, len(a)
+    sp = (C.c_void_p * n)(*[s.ptr for s in states])
+    r = ctx.lib.whisper_amd_full_batch(ctx.ptr, sp, n, params.c, ptrs, lens)
+    if r != 0:
+        raise WhisperError("GenericError(%d)" % r, r)
+    return r
 
 
 class WhisperState:
