@@ -125,6 +125,22 @@ def test_full_transcription_matches_reference_in_every_mode(env):
             st.free()
 
 
+def test_dtw_token_timestamps_match_reference(env):
+    """DTW token timestamps (BASELINE config 4): extra decoder pass capturing the alignment heads' cross-attention, then
+    normalise / median / mean / DTW on the host - every t_dtw identical to the reference engine's."""
+    import gen_golden_cases as cases
+    wrs, lib = env["wrs"], env["lib"]
+    for tag, preset, kw in cases.DTW_CASES:
+        ctx = wrs.WhisperContext.new_with_params(env["mp"], wrs.WhisperContextParameters(lib, dtw_preset=preset, **kw), lib=lib)
+        for aseed in (0, 1):
+            st = ctx.create_state()
+            st.full(wrs.FullParams(lib, 0, best_of=1, temperature_inc=0.0), wsynth.synth_audio(480000, aseed))
+            got = [dict(t0=s["t0"], t1=s["t1"], ids=s["ids"], t_dtw=s["t_dtw"]) for s in st.segments()]
+            assert got == env["gold"]["dtw"]["%s_seed%d" % (tag, aseed)], (tag, aseed)
+            st.free()
+        ctx.free()
+
+
 def test_state_carried_across_calls_and_short_inputs(env):
     wrs, lib, ctx, gold = env["wrs"], env["lib"], env["ctx"], env["gold"]
     st = ctx.create_state()

@@ -43,7 +43,7 @@ def segs_of(st):
                  p=[float(np.float32(x)) for x in s["p"]], plog=[float(np.float32(x)) for x in s["plog"]]) for s in st.segments()]
 
 
-from gen_golden_cases import FULL_CASES  # noqa: E402
+from gen_golden_cases import FULL_CASES, DTW_CASES  # noqa: E402
 
 
 def main():
@@ -117,6 +117,16 @@ def main():
             st.full(fp, wsynth.synth_audio(n, 7))
             gold["full"]["short_" + tag] = segs_of(st)
             st.free()
+        # DTW token timestamps (config 4): separate contexts with alignment heads (N top-most layers / a custom list)
+        gold["dtw"] = {}
+        for tag, preset, kw in DTW_CASES:
+            dctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(ref, use_gpu=False, dtw_preset=preset, **kw), lib=ref)
+            for aseed in (0, 1):
+                st = dctx.create_state()
+                st.full(W.FullParams(ref, 0, n_threads=8, best_of=1, temperature_inc=0.0), wsynth.synth_audio(480000, aseed))
+                gold["dtw"]["%s_seed%d" % (tag, aseed)] = [dict(t0=s_["t0"], t1=s_["t1"], ids=s_["ids"], t_dtw=s_["t_dtw"]) for s_ in st.segments()]
+                st.free()
+            dctx.free()
         json.dump(gold, open(os.path.join(OUT, shape + ".json"), "w"), indent=1)
         np.savez_compressed(os.path.join(OUT, shape + "_samples.npz"), **samples)
         print(shape, "done:", {k: len(v) for k, v in gold["full"].items()})

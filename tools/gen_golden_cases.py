@@ -10,3 +10,9 @@ FULL_CASES = {
     "greedy_prompt_context": dict(strategy=0, best_of=1, temperature_inc=0.0, no_context=False, prompt_tokens=[500, 600, 700, 800]),
     "greedy_suppress_nst_translate": dict(strategy=0, best_of=1, temperature_inc=0.0, suppress_nst=True, translate=True, language="de"),
 }
+
+# (tag, whisper_alignment_heads_preset, WhisperContextParameters kwargs): 1 = N_TOP_MOST, 2 = CUSTOM
+DTW_CASES = [
+    ("ntop2", 1, dict(dtw_n_top=2)),
+    ("custom", 2, dict(dtw_heads=[(1, 0), (2, 1), (2, 0)])),
+]

@@ -131,8 +131,8 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
             ln_linear(s, ctx.exact, WA_EPI_F16, st.d_dx, d, L.cross_ln, hp.eps, st.d_dxn, L.cross_q, n_tokens, nullptr, e);
         }
         float * qk_out = nullptr;
-        if (save_aheads && st.d_aheads_qk && il < (int) st.aheads.size() && !st.aheads[il].empty())
-            qk_out = st.d_aheads_qk + (size_t) il * n_tokens * H * T;
+        if (save_aheads && st.d_aheads_qk && il < (int) st.aheads_slot.size() && st.aheads_slot[il] >= 0)
+            qk_out = st.d_aheads_qk + (size_t) st.aheads_slot[il] * n_tokens * H * T;
         wa_launch_attn_exact(s, st.d_dq, d, st.d_cross_k + il * cross_layer, (size_t) st.cross_tpad * 64, 64, st.d_cross_v + il * cross_layer,
                              (size_t) st.cross_tpad * 64, 64, H, n_tokens, T, nullptr, KQscale, st.d_att_partial, st.d_att_pleft, st.d_dao, d, qk_out);
         {
@@ -287,19 +287,3 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     *ms_per_step = ms / n_iters;
     return 0;
 }
-
-#ifdef WA_STAMP
-#include "wa_kernels.h"
-// temporary instrumentation entry: runs LN+GEMV (cross-q shape) and plain GEMV (out-proj shape) once with stamps
-extern "C" __attribute__((visibility("default"))) void whisper_amd_stamp_probe(struct whisper_context * ctx, struct whisper_state * st, unsigned long long * out) {
-    const auto & m = ctx->model; const int d = m.hp.n_text_state;
-    unsigned long long * dbg = nullptr; (void) hipMalloc((void **) &dbg, 256); (void) hipMemset(dbg, 0, 256);
-    const auto & L = m.dec[0];
-    { wa_epi e; e.bias = L.cross_q.b; e.out = st->d_dq; e.ldo = d; e.dbg = (float *) dbg;
-      wa_launch_ln_gemv_exact(st->stream, WA_EPI_F16, st->d_dx, d, nullptr, L.cross_ln.w, L.cross_ln.b, m.hp.eps, L.cross_q.w, d, 1, d, d, e); }
-    { wa_epi e; e.bias = L.out.b; e.out = st->d_dx; e.ldo = d; e.resid = st->d_dx; e.ldr = d; e.dbg = (float *) (dbg + 16);
-      wa_launch_gemv_exact(st->stream, WA_EPI_RESID, st->d_dao, d, nullptr, L.out.w, d, 1, d, d, e); }
-    (void) hipStreamSynchronize(st->stream);
-    (void) hipMemcpy(out, dbg, 256, hipMemcpyDeviceToHost); (void) hipFree(dbg);
-}
-#endif

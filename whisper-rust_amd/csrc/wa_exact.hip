@@ -563,7 +563,15 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
 #pragma unroll
             for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
             double sumf = (double) wa_tree32(s32);
-            for (int c = np; c < n_kv; ++c) sumf += (double) (h2f(vp[(size_t) c * v_row_stride + tid]) * h2f(p16[c]));
+            const int nl = n_kv - np;
+            float prod[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {     // leftover cells: loads first (independent), ordered F64 accumulation after
+                const int cc = c < nl ? c : 0;
+                prod[c] = h2f(vp[(size_t) (np + cc) * v_row_stride + tid]) * h2f(p16[np + cc]);
+            }
+#pragma unroll
+            for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
             out[(size_t) j * ldo + h * 64 + tid] = f2h((float) sumf);
         }
     } else {

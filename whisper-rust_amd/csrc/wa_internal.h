@@ -242,6 +242,7 @@ struct whisper_state {
 
     // DTW (ref: whisper.cpp:856-860, 946-948)
     std::vector<std::vector<int>> aheads;  // per text layer: list of heads
+    std::vector<int> aheads_slot;          // per text layer: slot in d_aheads_qk during the DTW pass (-1: none)
     std::vector<float> aheads_cross_QKs_data;
     int aheads_n = 0;
 };
