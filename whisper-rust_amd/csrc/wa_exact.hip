@@ -130,18 +130,36 @@ __device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float 
     return lo == hi;
 }
 
+// In-order F64 sum of an LDS-resident row by one lane (the certificate's fallback): b128 reads pipeline, the 8-cycle
+// dependent F64 adds are all that is left (~3 us for 768 elements; the same loop over global memory took ~60 us).
+__device__ __forceinline__ double wa_seq_sum_lds(const float * row, int d, bool squares, float mean) {
+    double t = 0.0;
+    int i = 0;
+    for (; i + 4 <= d; i += 4) {
+        const float4 v = *(const float4 *) (row + i);
+        if (!squares) { t += (double) v.x; t += (double) v.y; t += (double) v.z; t += (double) v.w; }
+        else {
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+            t += (double) (a * a); t += (double) (b * b); t += (double) (c * c); t += (double) (e * e);
+        }
+    }
+    for (; i < d; ++i) { const float a = row[i] - mean; t += squares ? (double) (a * a) : (double) row[i]; }
+    return t;
+}
+
 // LayerNorm statistics of one row by one wave, reference-order semantics.  The row is read ONCE into registers
-// (NPL values per lane, d <= 64 * NPL); returns mean and scale.
+// (NPL values per lane, d <= 64 * NPL) and mirrored into `lrow` (LDS, d floats) for the fallback; returns mean and scale.
 #define LN_NPL 20
-__device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d, float eps, int lane, float (&xv)[LN_NPL], float & mean, float & scale) {
+__device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d, float eps, int lane, float * lrow, float (&xv)[LN_NPL],
+                                            float & mean, float & scale) {
     double s = 0.0, a = 0.0;
 #pragma unroll
-    for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? xr[i] : 0.0f; }
+    for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? xr[i] : 0.0f; if (i < d) lrow[i] = xv[k]; }
 #pragma unroll
     for (int k = 0; k < LN_NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }    // padding adds exact zeros
     s = wave_sum_d(s); a = wave_sum_d(a);
     if (!wa_sum_certain(s, a, d, mean)) {
-        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) t += (double) xr[i]; s = t; }
+        if (lane == 0) s = wa_seq_sum_lds(lrow, d, false, 0.0f);
         s = __shfl(s, 0, WAVE);
         mean = (float) (s / (double) d);
     }
@@ -151,7 +169,7 @@ __device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d
     s2 = wave_sum_d(s2);
     float variance;
     if (!wa_sum_certain(s2, s2, d, variance)) {
-        if (lane == 0) { double t = 0.0; for (int i = 0; i < d; ++i) { const float v = xr[i] - mean; t += (double) (v * v); } s2 = t; }
+        if (lane == 0) s2 = wa_seq_sum_lds(lrow, d, true, mean);
         s2 = __shfl(s2, 0, WAVE);
         variance = (float) (s2 / (double) d);
     }
@@ -161,12 +179,13 @@ __device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d
 __global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
                                                          const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
                                                          float * __restrict__ out32, int ld32) {
+    __shared__ __attribute__((aligned(16))) float lrows[4][64 * LN_NPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const float * xr = x + (size_t) row * ldx;
     float xv[LN_NPL], mean, scale;
-    wa_ln_stats(xr, d, eps, lane, xv, mean, scale);
+    wa_ln_stats(xr, d, eps, lane, lrows[wave], xv, mean, scale);
 #pragma unroll
     for (int k = 0; k < LN_NPL; ++k) {
         const int i = lane + 64 * k;
@@ -204,7 +223,7 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 // Block-wide LayerNorm of one F32 row (reference-order semantics, certified F64 sums), written as F16 into `dst`.
 // All 256 threads share the row, so each touches K/256 elements: the prologue is issue-bound, not bandwidth-bound.
 __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr, int K, const wa_ln_in & ln, wa_f16 * __restrict__ dst,
-                                                   double * __restrict__ red /*[16] shared*/, int tid) {
+                                                   double * __restrict__ red /*[16] shared*/, float * __restrict__ lrow /*[K] shared*/, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     float xv[GEMV_LN_NPL], gw[GEMV_LN_NPL], gb[GEMV_LN_NPL];
 #pragma unroll
@@ -212,6 +231,7 @@ __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr
         const int i = tid + GEMV_THREADS * k;
         const bool ok = i < K;
         xv[k] = ok ? xr[i] : 0.0f; gw[k] = ok ? ln.w[i] : 0.0f; gb[k] = ok ? ln.b[i] : 0.0f;
+        if (ok) lrow[i] = xv[k];
     }
     double s = 0.0, a = 0.0;
 #pragma unroll
@@ -223,7 +243,7 @@ __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr
     a = (red[4] + red[5]) + (red[6] + red[7]);
     float mean;
     if (!wa_sum_certain(s, a, K, mean)) {          // block-uniform decision
-        if (tid == 0) { double t = 0.0; for (int i = 0; i < K; ++i) t += (double) xr[i]; red[8] = t; }
+        if (tid == 0) red[8] = wa_seq_sum_lds(lrow, K, false, 0.0f);
         __syncthreads();
         mean = (float) (red[8] / (double) K);
     }
@@ -236,7 +256,7 @@ __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr
     s2 = (red[12] + red[13]) + (red[14] + red[15]);
     float variance;
     if (!wa_sum_certain(s2, s2, K, variance)) {
-        if (tid == 0) { double t = 0.0; for (int i = 0; i < K; ++i) { const float v = xr[i] - mean; t += (double) (v * v); } red[9] = t; }
+        if (tid == 0) red[9] = wa_seq_sum_lds(lrow, K, true, mean);
         __syncthreads();
         variance = (float) (red[9] / (double) K);
     }
@@ -260,6 +280,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
                                                              const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
     extern __shared__ __attribute__((aligned(16))) wa_f16 xs[];   // [MT][K]
     __shared__ double red[16];
+    __shared__ __attribute__((aligned(16))) float lrow[GEMV_THREADS * GEMV_LN_NPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = lane & 7, slot = lane >> 3;
     const int nsteps = K >> 5;
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
         for (int m = 0; m < MT; ++m) {
             if (m < M) {
                 const int src = rows ? rows[m] : m;
-                wa_block_layernorm(ln.x + (size_t) src * ln.ldx, K, ln, xs + (size_t) m * K, red, tid);
+                wa_block_layernorm(ln.x + (size_t) src * ln.ldx, K, ln, xs + (size_t) m * K, red, lrow, tid);
             } else {
                 for (int i = tid; i < K; i += GEMV_THREADS) xs[(size_t) m * K + i] = 0;
             }
