@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--chunks-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flash-attn", type=int, default=1, help="1 = MFMA fast path (default), 0 = reference-order path")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,8 +93,15 @@ def main():
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        n_dev = torch.cuda.device_count()
+        local_dev = local_rank % max(1, n_dev)          # rehearsal: several ranks may share one card
+        torch.cuda.set_device(local_dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(args.dist_backend)
+    else:
+        local_dev = local_rank
 
     def barrier():
         if dist is not None:
@@ -101,7 +109,7 @@ def main():
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per concurrent chunk stream
     hip = Hip()
-    hip.set_device(local_rank)
+    hip.set_device(local_dev)
     lib = W.load_library()          # fails loudly if the HIP library is missing
     W.set_log_callback(lib, lambda lvl, txt: sys.stderr.write(txt) if lvl >= 3 else None)
     shape = wsynth.SHAPES[args.model]
@@ -111,21 +119,22 @@ def main():
         mp = wsynth.model_path(args.model)
     if world > 1:
         import torch
+        cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
         if rank == 0:
-            img = torch.from_numpy(np.fromfile(mp, dtype=np.uint8)).cuda()
-            n = torch.tensor([img.numel()], dtype=torch.int64, device="cuda")
+            img = torch.from_numpy(np.fromfile(mp, dtype=np.uint8)).to(cdev)
+            n = torch.tensor([img.numel()], dtype=torch.int64, device=cdev)
         else:
-            n = torch.zeros(1, dtype=torch.int64, device="cuda")
+            n = torch.zeros(1, dtype=torch.int64, device=cdev)
         dist.broadcast(n, 0)
         if rank != 0:
-            img = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
+            img = torch.empty(int(n.item()), dtype=torch.uint8, device=cdev)
         dist.broadcast(img, 0)
         buf = img.cpu().numpy().tobytes()
         ctx = W.WhisperContext.new_from_buffer_with_params(
-            buf, W.WhisperContextParameters(lib, gpu_device=local_rank, flash_attn=bool(args.flash_attn)), lib=lib)
+            buf, W.WhisperContextParameters(lib, gpu_device=local_dev, flash_attn=bool(args.flash_attn)), lib=lib)
         del img, buf
     else:
-        ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib, gpu_device=local_rank, flash_attn=bool(args.flash_attn)), lib=lib)
+        ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib, gpu_device=local_dev, flash_attn=bool(args.flash_attn)), lib=lib)
 
     n_chunks = args.chunks_per_gpu
     states = [ctx.create_state() for _ in range(n_chunks)]
@@ -153,10 +162,11 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tk = torch.tensor([ntok], dtype=torch.int64, device="cuda")
+        tk = torch.tensor([ntok], dtype=torch.int64, device=cdev)
         dist.all_reduce(tk)
         ntok_all = int(tk.item())
     else:
