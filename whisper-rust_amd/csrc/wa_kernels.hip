@@ -7,6 +7,7 @@
 // rounds at exactly those points; only the F32 summation ORDER differs (MFMA / wave reductions).
 // The file is compiled with -ffp-contract=off: an fma appears only where it is written.
 #include "wa_device.h"
+#include <cstdlib>
 
 // =================================================================================================
 // MFMA GEMM: C = A * W^T, both operands K-contiguous F16, F32 accumulate (v_mfma_f32_16x16x32_f16).
@@ -128,7 +129,8 @@ void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int 
                     const wa_epi & e) {
     // 128x128 tiles when that still yields >= 256 blocks (one per CU); 64x64 otherwise.
     const long big = (long) ((M + 127) / 128) * ((N + 127) / 128);
-    if (big >= 256) gemm_dispatch<128, 128>(stream, mode, A, lda, W, ldw, M, N, K, e);
+    static const long thr = getenv("WHISPER_AMD_GEMM_THR") ? atol(getenv("WHISPER_AMD_GEMM_THR")) : 1000000;   // measured on ggml-small shapes (M = 1500): 64x64 tiles (>= 4 blocks per CU) beat 128x128 on every GEMM of the encoder
+    if (big >= thr) gemm_dispatch<128, 128>(stream, mode, A, lda, W, ldw, M, N, K, e);
     else            gemm_dispatch<64, 64>(stream, mode, A, lda, W, ldw, M, N, K, e);
 }
 
@@ -358,7 +360,7 @@ __global__ void k_mel_norm(float * __restrict__ mel, size_t n, const unsigned in
 
 void wa_launch_mel(hipStream_t stream, const float * pcm, int n_samples, const float * hann, const float * sincos,
                    const float * filters, int n_mel, int n_fft_bins, float * mel, int n_len, unsigned int * mel_max) {
-    hipMemsetAsync(mel_max, 0, sizeof(unsigned int), stream);
+    (void) hipMemsetAsync(mel_max, 0, sizeof(unsigned int), stream);
     int n_active = (n_samples + 200) / 160 + 1;
     if (n_active > n_len) n_active = n_len;
     hipLaunchKernelGGL(k_mel_frames, dim3(n_len), dim3(256), 0, stream, pcm, n_samples, hann, sincos, filters, n_mel, n_fft_bins, mel,
@@ -437,6 +439,9 @@ void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows,
 // =================================================================================================
 #define ATT_LD 72
 
+// flash path only: hardware exp2 (v_exp_f32, ~1 ulp) instead of the reference's 25-instruction polynomial
+__device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk, int ldqk, const wa_f16 * __restrict__ vt, int ldvt, int T,
                                                   int d, float scale, wa_f16 * __restrict__ out, int ldo) {
     __shared__ __attribute__((aligned(16))) wa_f16 Ks[64 * ATT_LD];
@@ -505,10 +510,10 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
             const float m_new = fmaxf(m_run[r], mx);
-            float ls = wa_expf(s[0][r] - m_new) + wa_expf(s[1][r] - m_new) + wa_expf(s[2][r] - m_new) + wa_expf(s[3][r] - m_new);
+            float ls = fast_expf(s[0][r] - m_new) + fast_expf(s[1][r] - m_new) + fast_expf(s[2][r] - m_new) + fast_expf(s[3][r] - m_new);
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) ls += __shfl_xor(ls, o, WAVE);
-            const float corr = (m_run[r] == -INFINITY) ? 0.f : wa_expf(m_run[r] - m_new);
+            const float corr = (m_run[r] == -INFINITY) ? 0.f : fast_expf(m_run[r] - m_new);
             l_run[r] = l_run[r] * corr + ls;
             m_run[r] = m_new;
         }
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = wa_expf(s[nt][r] - m_run[r]) * inv_l[r];
+                const float p = fast_expf(s[nt][r] - m_run[r]) * inv_l[r];
                 Ps[wave][(fg * 4 + r) * ATT_LD + nt * 16 + fr] = f2h(p);
             }
         __syncthreads();
