@@ -465,6 +465,19 @@ WHISPER_API int whisper_amd_decoder_info(struct whisper_state * state, int j, do
  * Needs a prior whisper_encode*; touches KV cell `n_past` of the state.  0 on success. */
 WHISPER_API int whisper_amd_decode_step_probe(struct whisper_context * ctx, struct whisper_state * state, int n_past, int n_iters, float * ms_per_step);
 
+/* 1 when the state runs the single-token decoder pass as ONE persistent launch (wa_mega.hip), 0 when it replays the
+ * captured launch sequence (WHISPER_AMD_NO_MEGA=1, unsupported shape, or after a hand-off time-out). */
+WHISPER_API int whisper_amd_mega_enabled(struct whisper_state * state);
+
+/* Debugging aid (tools/mega_check.py): runs the one-launch step for (token, position n_past) on KV cell n_past and copies
+ * out the hand-off granules [n_text_layer][8][2 * n_text_state] (tag << 32 | value bits) and the logits [n_vocab].
+ * Returns the step's status word (0 = ok), < 0 when the one-launch step is not available. */
+WHISPER_API int whisper_amd_mega_debug(struct whisper_context * ctx, struct whisper_state * state, int token, int n_past,
+                                       unsigned long long * granules_out, float * logits_out);
+/* The same step through the launch sequence, stage by stage: values only, in the granule layout above (32-bit words). */
+WHISPER_API int whisper_amd_seq_debug(struct whisper_context * ctx, struct whisper_state * state, int token, int n_past, unsigned * values_out,
+                                      float * logits_out);
+
 /* Chunk-parallel transcription on ONE device: runs `n_chunks` independent whisper_full_with_state
  * jobs concurrently, each on its own state / HIP stream / host thread (the single-stream decode step is latency-bound
  * and fills a fraction of the chip, so the streams overlap).  samples[i] may be host or device pointers.

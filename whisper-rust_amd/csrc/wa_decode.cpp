@@ -5,9 +5,13 @@
 // whisper_decode_internal whisper.cpp:2864-2994.
 #include "wa_internal.h"
 #include "wa_kernels.h"
+#include "wa_mega.h"
 
 #include <cmath>
+#include <mutex>
 #include <cstring>
+#include <cstdlib>
+#include <cstdio>
 #include <limits>
 
 // -------------------------------------------------------------------------------------------------
@@ -157,6 +161,55 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// the single-token pass as ONE launch (wa_mega.hip).  Only one such launch may be in flight per device: its
+// workgroups wait for each other, so two of them interleaved by the dispatcher could each hold CUs the other needs.
+// Returns 1 = done (logits in h_logits_pinned), 0 = not applicable / gave up (caller runs the launch sequence).
+// -------------------------------------------------------------------------------------------------
+static std::mutex g_mega_mutex;
+
+static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & a, int token, int pos, int n_kv, int kv_head) {
+    const auto & m = ctx.model;
+    const auto & hp = m.hp;
+    const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
+    if (!st.mega_enabled || n_kv > WA_MEGA_MAX_KV || n_kv < 1 || kv_head < 0 || kv_head >= n_kv || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
+    a.layers = (const wa_mega_layer *) m.d_mega_layers;
+    a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps;
+    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu;
+    a.kv_k = st.kv_self.k; a.kv_v = st.kv_self.v; a.kv_layer_stride = (unsigned long long) st.kv_self.size * hp.n_text_state;
+    a.cross_k = st.d_cross_k; a.cross_v = st.d_cross_v;
+    a.cross_layer_stride = (unsigned long long) hp.n_text_head * st.cross_tpad * 64; a.cross_tpad = st.cross_tpad; a.T = T;
+    a.granules = st.d_mega_gr; a.edge_stride = 2 * hp.n_text_state;
+    a.logits = st.d_mega_out; a.status = st.d_mega_status; a.dbg = nullptr;
+    a.token = token; a.pos = pos; a.n_kv = n_kv; a.kv_head = kv_head;
+    a.kq_scale = pow(float(64), -0.25);       // whisper.cpp:2522
+    st.mega_seq += 1; if (st.mega_seq == 0) st.mega_seq = 1;
+    a.seq = st.mega_seq;
+    return true;
+}
+
+static int mega_step(whisper_context & ctx, whisper_state & st, int token, int pos, int n_kv, int kv_head) {
+    wa_mega_args a;
+    if (!mega_args(ctx, st, a, token, pos, n_kv, kv_head)) return 0;
+    const int n_vocab = ctx.model.hp.n_vocab;
+    hipStream_t s = st.stream;
+    unsigned status = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mega_mutex);
+        wa_launch_decode_mega(s, a, std::min(ctx.model.n_cu, 256));
+        (void) hipMemcpyAsync(st.h_logits_pinned, st.d_mega_out, ((size_t) n_vocab + 1) * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (!WA_HIP_OK(hipStreamSynchronize(s))) { st.mega_enabled = false; return 0; }
+        status = ((const unsigned *) st.h_logits_pinned)[n_vocab];
+    }
+    if (status != 0) {     // a hand-off timed out (workgroups not co-resident?): fall back for good
+        WA_WARN("%s: one-launch decode step gave up at hand-off %u - using the launch sequence from now on\n", __func__, status);
+        (void) hipMemsetAsync(st.d_mega_status, 0, sizeof(unsigned), s);
+        st.mega_enabled = false;
+        return 0;
+    }
+    return 1;
+}
+
 bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads, ggml_abort_callback abort_cb,
                void * abort_data) {
     const int64_t t0 = wa_time_us();
@@ -199,15 +252,20 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
         const int32_t pos = batch.pos[j], seq = batch.seq_id[j];
         for (int i = 0; i < n_kv; ++i) h_mask[(size_t) j * n_kv + i] = (!kv.cells[i].has(seq) || kv.cells[i].pos > pos) ? 1 : 0;
     }
+    // single token, every cell below n_kv visible (the greedy steady state): one persistent launch (wa_mega.hip), or - when that
+    // is not available - a replay of the captured hipGraph of the launch sequence
+    bool need_mask = false;
+    for (size_t i = 0; i < (size_t) n_tokens * n_kv && !need_mask; ++i) need_mask = h_mask[i] != 0;
+    const bool steady = n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads;
+    bool done = false;
+    if (steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    if (!done) {
     (void) hipMemcpyAsync(st.d_tok,  h_tok,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
     (void) hipMemcpyAsync(st.d_pos,  h_pos,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
     if (n_rows) (void) hipMemcpyAsync(st.d_rows, h_rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice, s);
     (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
 
-    // single token, every cell below n_kv visible (the greedy steady state): replay the captured hipGraph of the pass
-    bool need_mask = false;
-    for (size_t i = 0; i < (size_t) n_tokens * n_kv && !need_mask; ++i) need_mask = h_mask[i] != 0;
-    if (st.graphs_enabled && n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads) {
+    if (st.graphs_enabled && steady) {
         const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx;
         if (st.dec_graph && (st.dec_graph_T != T || st.dec_graph_kv_size != kv.size || st.dec_graph_kv_k != kv.k)) {
             (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr;
@@ -234,6 +292,7 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     }
     if (n_rows) (void) hipMemcpyAsync(st.h_logits_pinned, st.d_logits, (size_t) n_rows * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
+    }
     for (int r = 0; r < n_rows; ++r)
         memcpy(st.logits.data() + (size_t) h_rows[r] * n_vocab, st.h_logits_pinned + (size_t) r * n_vocab, n_vocab * sizeof(float));
 
@@ -264,6 +323,26 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     (void) hipMemcpyAsync(st->d_rows, h + 2, sizeof(int32_t), hipMemcpyHostToDevice, s);
     hipEvent_t e0, e1;
     if (!WA_HIP_OK(hipEventCreate(&e0)) || !WA_HIP_OK(hipEventCreate(&e1))) return -1;
+    if (st->mega_enabled) {     // the one-launch step: n_iters launches back to back, each with its own sequence number
+        wa_mega_args a;
+        if (mega_args(*ctx, *st, a, h[0], n_past, n_past + 1, n_past)) {
+            std::lock_guard<std::mutex> lk(g_mega_mutex);
+            const int n_wg = std::min(ctx->model.n_cu, 256);
+            wa_launch_decode_mega(s, a, n_wg);      // warm-up
+            (void) hipEventRecord(e0, s);
+            for (int i = 0; i < n_iters; ++i) { mega_args(*ctx, *st, a, h[0], n_past, n_past + 1, n_past); wa_launch_decode_mega(s, a, n_wg); }
+            (void) hipEventRecord(e1, s);
+            if (!WA_HIP_OK(hipEventSynchronize(e1))) return -1;
+            float ms = 0.f;
+            (void) hipEventElapsedTime(&ms, e0, e1);
+            (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+            unsigned status = 0;
+            (void) hipMemcpy(&status, st->d_mega_status, sizeof(status), hipMemcpyDeviceToHost);
+            if (status != 0) { (void) hipMemset(st->d_mega_status, 0, sizeof(unsigned)); st->mega_enabled = false; return -2; }
+            *ms_per_step = ms / n_iters;
+            return 0;
+        }
+    }
     h[3] = n_past + 1; h[4] = n_past;
     (void) hipMemcpyAsync(st->d_dyn, h + 3, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s);
     hipGraphExec_t ge = nullptr;
@@ -285,5 +364,96 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     if (ge) (void) hipGraphExecDestroy(ge);
     *ms_per_step = ms / n_iters;
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// debugging aid (tools/mega_check.py): run the one-launch step for (token, pos) on KV cell `n_past` and copy out the
+// hand-off granules [layer][8][2d] (tag << 32 | value) and the logits.  KV metadata is not touched.
+// -------------------------------------------------------------------------------------------------
+extern "C" int whisper_amd_mega_debug(struct whisper_context * ctx, struct whisper_state * st, int token, int n_past, unsigned long long * granules_out,
+                                      float * logits_out) {
+    static float * d_dbg = nullptr;
+    if (!ctx || !st || !st->mega_enabled) return -1;
+    if (!WA_HIP_OK(hipSetDevice(ctx->device))) return -1;
+    wa_mega_args a;
+    if (!mega_args(*ctx, *st, a, token, n_past, n_past + 1, n_past)) return -2;
+    const auto & hp = ctx->model.hp;
+    const size_t n_dbg = (size_t) hp.n_text_layer * hp.n_text_head * 5120;
+    if (getenv("WHISPER_AMD_MEGA_DBG")) { if (!d_dbg) (void) hipMalloc((void **) &d_dbg, n_dbg * 4); a.dbg = d_dbg; }
+    std::lock_guard<std::mutex> lk(g_mega_mutex);
+    wa_launch_decode_mega(st->stream, a, std::min(ctx->model.n_cu, 256));
+    if (!WA_HIP_OK(hipStreamSynchronize(st->stream))) return -3;
+    if (a.dbg) { std::vector<float> h(n_dbg); (void) hipMemcpy(h.data(), d_dbg, n_dbg * 4, hipMemcpyDeviceToHost); FILE * f = fopen("gpurun_out/mega_dbg.bin", "wb"); if (f) { fwrite(h.data(), 4, n_dbg, f); fclose(f); } }
+    if (granules_out) (void) hipMemcpy(granules_out, st->d_mega_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * 2 * hp.n_text_state * 8, hipMemcpyDeviceToHost);
+    if (logits_out) (void) hipMemcpy(logits_out, st->d_mega_out, (size_t) hp.n_vocab * 4, hipMemcpyDeviceToHost);
+    unsigned status = 0;
+    (void) hipMemcpy(&status, st->d_mega_status, 4, hipMemcpyDeviceToHost);
+    return (int) status;
+}
+
+extern "C" int whisper_amd_mega_enabled(struct whisper_state * st) { return st && st->mega_enabled ? 1 : 0; }
+
+// The same step through the launch sequence, stage by stage, with every stage's output copied out in the granule
+// layout of whisper_amd_mega_debug (values only: F32 bits, or two F16 per word) - to localise a difference.
+extern "C" int whisper_amd_seq_debug(struct whisper_context * ctxp, struct whisper_state * stp, int token, int n_past, unsigned * values_out,
+                                     float * logits_out) {
+    if (!ctxp || !stp) return -1;
+    whisper_context & ctx = *ctxp; whisper_state & st = *stp;
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return -1;
+    const auto & m = ctx.model; const auto & hp = m.hp;
+    const int d = hp.n_text_state, H = hp.n_text_head, n_kv = n_past + 1, kv_head = n_past;
+    const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx;
+    hipStream_t s = st.stream;
+    auto & kv = st.kv_self;
+    const int32_t h3[3] = { token, n_past, 0 };
+    (void) hipMemcpy(st.d_tok, &h3[0], 4, hipMemcpyHostToDevice);
+    (void) hipMemcpy(st.d_pos, &h3[1], 4, hipMemcpyHostToDevice);
+    (void) hipMemcpy(st.d_rows, &h3[2], 4, hipMemcpyHostToDevice);
+    const size_t es = (size_t) 2 * d;
+    auto out = [&](int l, int e) { return values_out + ((size_t) l * 8 + e) * es; };
+    float * d_qk = nullptr; std::vector<float> h_qk, h_part;
+    if (getenv("WHISPER_AMD_MEGA_DBG")) { (void) hipMalloc((void **) &d_qk, (size_t) H * T * 4); h_qk.resize((size_t) hp.n_text_layer * H * T); h_part.resize((size_t) hp.n_text_layer * H * 2048); }
+    auto grab = [&](unsigned * dst, const void * src, size_t bytes) { (void) hipStreamSynchronize(s); (void) hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
+    wa_launch_dec_embed(s, st.d_tok, st.d_pos, 1, d, m.d_te, m.d_pe, st.d_dx);
+    const float KQscale = pow(float(64), -0.25);
+    const size_t kv_layer = (size_t) kv.size * d, cross_layer = (size_t) H * st.cross_tpad * 64;
+    for (int il = 0; il < hp.n_text_layer; ++il) {
+        const auto & L = m.dec[il];
+        {
+            wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
+            e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
+            e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
+            ln_linear(s, true, WA_EPI_DEC_QKV, st.d_dx, d, L.attn_ln, hp.eps, st.d_dxn, L.qkv, 1, nullptr, e);
+        }
+        grab(out(il, 0), st.d_dq, (size_t) d * 2);
+        grab(out(il, 0) + d / 2, kv.k + il * kv_layer + (size_t) kv_head * d, (size_t) d * 2);
+        grab(out(il, 0) + d, kv.v + il * kv_layer + (size_t) kv_head * d, (size_t) d * 2);
+        wa_launch_attn_exact(s, st.d_dq, d, kv.k + il * kv_layer, 64, d, kv.v + il * kv_layer, 64, d, H, 1, n_kv, nullptr, 1.0f,
+                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr, nullptr);
+        grab(out(il, 1), st.d_dao, (size_t) d * 2);
+        { wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; linear(s, true, WA_EPI_RESID, st.d_dao, d, L.out, 1, e); }
+        grab(out(il, 2), st.d_dx, (size_t) d * 4);
+        { wa_epi e; e.bias = L.cross_q.b; e.out = st.d_dq; e.ldo = d; ln_linear(s, true, WA_EPI_F16, st.d_dx, d, L.cross_ln, hp.eps, st.d_dxn, L.cross_q, 1, nullptr, e); }
+        grab(out(il, 3), st.d_dq, (size_t) d * 2);
+        wa_launch_attn_exact(s, st.d_dq, d, st.d_cross_k + il * cross_layer, (size_t) st.cross_tpad * 64, 64, st.d_cross_v + il * cross_layer,
+                             (size_t) st.cross_tpad * 64, 64, H, 1, T, nullptr, KQscale, st.d_att_partial, st.d_att_pleft, st.d_dao, d, d_qk);
+        grab(out(il, 4), st.d_dao, (size_t) d * 2);
+        if (d_qk) (void) hipMemcpy(h_qk.data() + (size_t) il * H * T, d_qk, (size_t) H * T * 4, hipMemcpyDeviceToHost);
+        if (d_qk) (void) hipMemcpy(h_part.data() + (size_t) il * H * 2048, st.d_att_partial, (size_t) H * 2048 * 4, hipMemcpyDeviceToHost);
+        { wa_epi e; e.bias = L.cross_out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; linear(s, true, WA_EPI_RESID, st.d_dao, d, L.cross_out, 1, e); }
+        grab(out(il, 5), st.d_dx, (size_t) d * 4);
+        { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_dff; e.ldo = 4 * d; ln_linear(s, true, WA_EPI_GELU_F16, st.d_dx, d, L.mlp_ln, hp.eps, st.d_dxn, L.fc1, 1, nullptr, e); }
+        grab(out(il, 6), st.d_dff, (size_t) 4 * d * 2);
+        { wa_epi e; e.bias = L.fc2.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; linear(s, true, WA_EPI_RESID, st.d_dff, 4 * d, L.fc2, 1, e); }
+        grab(out(il, 7), st.d_dx, (size_t) d * 4);
+    }
+    {
+        wa_epi e; e.out = st.d_logits; e.ldo = hp.n_vocab;
+        wa_launch_ln_gemv_exact(s, WA_EPI_F32, st.d_dx, d, st.d_rows, m.d_ln.w, m.d_ln.b, hp.eps, m.d_te, d, 1, hp.n_vocab, d, e);
+    }
+    if (logits_out) grab((unsigned *) logits_out, st.d_logits, (size_t) hp.n_vocab * 4);
+    if (d_qk) { FILE * f = fopen("gpurun_out/seq_dbg.bin", "wb"); if (f) { fwrite(h_qk.data(), 4, h_qk.size(), f); fclose(f); } (void) hipFree(d_qk); }
+    if (d_qk) { FILE * f = fopen("gpurun_out/seq_part.bin", "wb"); if (f) { fwrite(h_part.data(), 4, h_part.size(), f); fclose(f); } }
     return 0;
 }

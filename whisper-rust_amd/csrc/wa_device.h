@@ -15,7 +15,10 @@ typedef float    f32x4 __attribute__((ext_vector_type(4)));
 #define WAVE 64
 
 __device__ __forceinline__ float h2f(wa_f16 v) { union { wa_f16 u; h16 h; } c; c.u = v; return (float) c.h; }
-__device__ __forceinline__ wa_f16 f2h(float v) { union { wa_f16 u; h16 h; } c; c.h = (h16) v; return c.u; }   // RNE
+// RNE from the F32 VALUE.  The empty asm makes `v` opaque: without it hipcc folds f16(a * b) / f16(a + b) into one
+// v_fma_mixlo_f16, which rounds the exact result ONCE - not the reference's round-to-F32-then-to-F16 (seen as a 1-ulp
+// different soft-max probability every few thousand values).
+__device__ __forceinline__ wa_f16 f2h(float v) { asm("" : "+v"(v)); union { wa_f16 u; h16 h; } c; c.h = (h16) v; return c.u; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -186,3 +189,39 @@ __device__ __forceinline__ float wa_expf_libm(float x) {
     y = y * s;
     return (float) y;
 }
+
+// -------------------------------------------------------------------------------------------------
+// certified F64 sums (LayerNorm / soft-max denominators), shared by wa_exact.hip and wa_mega.hip
+// -------------------------------------------------------------------------------------------------
+// The reference sums a row in index order in F64 (ops.cpp:3225-3237).  A wave sums it in another order; the two
+// F64 results can differ by at most delta = 2 n u sum|x| (u = 2^-53).  Rounding to F32 after the division is
+// monotonic, so when (S - delta)/n and (S + delta)/n round to the SAME float, that float is the reference's
+// value whatever its order was.  Otherwise (probability ~ n 2^-27 per row) one lane redoes the sum in index order.
+__device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out) {
+    // conservative bounds of (S -+ delta)/n by multiplication (1/n in F64 is within 2^-53; the 2^-48 slack covers it):
+    // if both bounds round to the same float, the correctly rounded quotient of any sum in the interval does too.
+    const double rn = 1.0 / (double) n;
+    const double delta = (2.0 * (double) n * 0x1p-53 * A + fabs(S) * 0x1p-48) * rn * 1.000001;
+    const double q = S * rn;
+    const float lo = (float) (q - delta), hi = (float) (q + delta);
+    out = lo;
+    return lo == hi;
+}
+
+// In-order F64 sum of an LDS-resident row by one lane (the certificate's fallback): b128 reads pipeline, the 8-cycle
+// dependent F64 adds are all that is left (~3 us for 768 elements; the same loop over global memory took ~60 us).
+__device__ __forceinline__ double wa_seq_sum_lds(const float * row, int d, bool squares, float mean) {
+    double t = 0.0;
+    int i = 0;
+    for (; i + 4 <= d; i += 4) {
+        const float4 v = *(const float4 *) (row + i);
+        if (!squares) { t += (double) v.x; t += (double) v.y; t += (double) v.z; t += (double) v.w; }
+        else {
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+            t += (double) (a * a); t += (double) (b * b); t += (double) (c * c); t += (double) (e * e);
+        }
+    }
+    for (; i < d; ++i) { const float a = row[i] - mean; t += squares ? (double) (a * a) : (double) row[i]; }
+    return t;
+}
+

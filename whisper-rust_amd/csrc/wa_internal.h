@@ -103,6 +103,8 @@ struct wa_model {
     wa_ln  d_ln;
     std::vector<wa_dec_layer> dec;
     wa_lin cross_kv;                      // fused over ALL decoder layers: [L*2d][d]; per column bias+scale
+    void * d_mega_layers = nullptr;       // device table of wa_mega_layer (wa_mega.h): per-layer pointers for the one-launch decode step
+    int    n_cu = 0;                      // compute units of the device (= workgroups of the one-launch decode step)
 };
 
 struct whisper_context {
@@ -225,6 +227,13 @@ struct whisper_state {
     hipGraphExec_t dec_graph = nullptr;
     int dec_graph_T = 0; uint32_t dec_graph_kv_size = 0; const void * dec_graph_kv_k = nullptr;
     bool graphs_enabled = true;
+
+    // one-launch decode step (wa_mega.hip): hand-off granules [layer][8][2d], status word, launch sequence number
+    unsigned long long * d_mega_gr = nullptr;
+    float * d_mega_out = nullptr;         // [n_vocab] logits + status word
+    unsigned * d_mega_status = nullptr;   // = d_mega_out + n_vocab
+    unsigned mega_seq = 0;
+    bool mega_enabled = false;
 
     // pinned host staging
     int32_t * h_stage_i32 = nullptr; int8_t * h_stage_mask = nullptr; size_t h_mask_cap = 0;

@@ -12,6 +12,7 @@
 //   * conv weights re-ordered k-major ([oc][k][ic]) so conv1/conv2 read the activations as a plain
 //     strided view (no im2col buffer), conv1's K padded to a multiple of 32 with zeros.
 #include "wa_internal.h"
+#include "wa_mega.h"
 
 #include <cmath>
 #include <cstring>
@@ -47,6 +48,7 @@ struct arena_builder {
 } // namespace
 
 void wa_model_free(whisper_context & ctx) {
+    if (ctx.model.d_mega_layers) { (void) hipFree(ctx.model.d_mega_layers); ctx.model.d_mega_layers = nullptr; }
     if (ctx.model.arena) { (void) hipFree(ctx.model.arena); ctx.model.arena = nullptr; }
 }
 
@@ -379,6 +381,26 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
         L.fc1 = LIN(dof[i].fc1, 4 * d, d); L.fc2 = LIN(dof[i].fc2, d, 4 * d);
     }
     model.cross_kv = LIN(lin_off{ o_ckv_w, o_ckv_b, o_ckv_s }, Ld * 2 * d, d);
+
+    {   // per-layer pointer table of the one-launch decode step (wa_mega.hip)
+        std::vector<wa_mega_layer> tab(Ld);
+        for (int i = 0; i < Ld; ++i) {
+            const auto & L = model.dec[i];
+            wa_mega_layer & t = tab[i];
+            t.ln1_w = L.attn_ln.w;  t.ln1_b = L.attn_ln.b;  t.qkv_w = L.qkv.w; t.qkv_b = L.qkv.b; t.qkv_s = L.qkv.s;
+            t.out_w = L.out.w;      t.out_b = L.out.b;
+            t.ln2_w = L.cross_ln.w; t.ln2_b = L.cross_ln.b; t.cq_w = L.cross_q.w; t.cq_b = L.cross_q.b;
+            t.co_w  = L.cross_out.w; t.co_b = L.cross_out.b;
+            t.ln3_w = L.mlp_ln.w;   t.ln3_b = L.mlp_ln.b;   t.fc1_w = L.fc1.w; t.fc1_b = L.fc1.b;
+            t.fc2_w = L.fc2.w;      t.fc2_b = L.fc2.b;
+        }
+        if (Ld > 0) {
+            if (!WA_HIP_OK(hipMalloc(&model.d_mega_layers, tab.size() * sizeof(wa_mega_layer)))) return false;
+            if (!WA_HIP_OK(hipMemcpy(model.d_mega_layers, tab.data(), tab.size() * sizeof(wa_mega_layer), hipMemcpyHostToDevice))) return false;
+        }
+        hipDeviceProp_t prop;
+        if (WA_HIP_OK(hipGetDeviceProperties(&prop, wctx.device))) model.n_cu = prop.multiProcessorCount;
+    }
 
     wctx.t_load_us = wa_time_us() - t_start;
     return true;

@@ -1,0 +1,43 @@
+// wa_mega.h - the single-token decode step as ONE persistent launch (wa_mega.hip).
+//
+// ref: whisper_build_graph_decoder whisper.cpp:2474-2852 for n_tokens == 1 (the greedy steady state).
+// The launch sequence of wa_decode.cpp (122 dependent launches, each a few microseconds of fill / drain around
+// < 1 us of streaming) becomes one grid of one workgroup per CU whose workgroups hand activations to each other
+// through 8-byte {tag, value} granules (write-through stores, polled loads) and prefetch everything that does
+// not depend on the token (weights, self / cross K and V) ahead of the hand-off that needs it.
+#pragma once
+#include "wa_kernels.h"
+
+struct wa_mega_layer {          // device-resident table, one entry per decoder layer (pointers into the model arena)
+    const float * ln1_w, * ln1_b; const wa_f16 * qkv_w; const float * qkv_b, * qkv_s;    // [3d][d], bias (0 for k), column scale
+    const wa_f16 * out_w;  const float * out_b;
+    const float * ln2_w, * ln2_b; const wa_f16 * cq_w;  const float * cq_b;
+    const wa_f16 * co_w;   const float * co_b;
+    const float * ln3_w, * ln3_b; const wa_f16 * fc1_w; const float * fc1_b;
+    const wa_f16 * fc2_w;  const float * fc2_b;
+};
+
+struct wa_mega_args {
+    // model
+    const wa_mega_layer * layers; int n_layer, d, n_head, n_vocab; float eps;
+    const wa_f16 * te; const float * pe; const float * lnf_w, * lnf_b; const wa_f16 * gelu;
+    // state
+    wa_f16 * kv_k, * kv_v; unsigned long long kv_layer_stride;                  // self K/V [layer][cell][d]
+    const wa_f16 * cross_k, * cross_v; unsigned long long cross_layer_stride;   // cross K/V [layer][head][tpad][64]
+    int cross_tpad, T;
+    unsigned long long * granules; int edge_stride;                            // [layer][8][edge_stride] hand-off granules
+    float * logits;                                                             // [n_vocab]
+    unsigned * status;                                                          // 0 = ok; else code of the hand-off that timed out
+    float * dbg;                                                                // optional [layer][head][2][1536]: cross-attention scores, probabilities
+    // launch
+    int token, pos, n_kv, kv_head; unsigned seq; float kq_scale;
+};
+
+#define WA_MEGA_EDGES 8
+#define WA_MEGA_MAX_D 1280
+#define WA_MEGA_MAX_KV 512
+#define WA_MEGA_MAX_T 1536
+
+// n_wg workgroups of 512 threads, every one of them resident at once (n_wg <= number of CUs; 1 workgroup per CU)
+void   wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg);
+size_t wa_mega_lds_bytes();

@@ -1,0 +1,770 @@
+// wa_mega.hip - the single-token decode step (whisper.cpp:2474-2852, n_tokens == 1) as ONE launch.
+//
+// Why: the step streams 335 MB (ggml-small) = 53 us of HBM time, but as 122 dependent launches it took 760 us: every
+// launch pays its own fill / drain and cannot fetch a byte before its predecessor has finished.  Here one grid of one
+// 512-thread workgroup per CU stays resident for the whole step:
+//   * work is partitioned statically: GEMV workgroups own a slice of the rows of EVERY matrix, H workgroups own one
+//     self-attention head each, H more own one cross-attention head each;
+//   * everything that does not depend on the token - weights, the self K/V cells of earlier tokens, the encoder K/V -
+//     is loaded ahead of the hand-off that needs it (into VGPRs or LDS), so a phase costs one hand-off plus arithmetic;
+//   * activations travel between workgroups as 8-byte {tag = launch sequence number, value} granules written with
+//     write-through (sc1) stores and polled with sc1 loads: the data is its own flag, no fences, no barrier kernel
+//     (MI355X guide, Guideline 16 form R2).  Every poll is bounded and reports a time-out through `status`.
+// All arithmetic is the reference order of wa_exact.hip (ggml_vec_dot_f16 chains and tree, ops.cpp soft_max, certified
+// F64 LayerNorm sums): the logits are bit-identical to the launch-sequence path and to whisper.cpp CPU.
+#include "wa_device.h"
+#include "wa_mega.h"
+
+typedef unsigned long long u64;
+#define GAS __attribute__((address_space(1)))
+typedef GAS u64 gu64;
+typedef GAS unsigned gu32;
+typedef const GAS wa_f16 * gch;      // every global access is spelled global: a pointer read from the argument block or from
+typedef const GAS float * gcf;       // the layer table is generic to the compiler, and a flat access also waits on the LDS counter
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (HIP's u32x4 class cannot be read through an address-space pointer)
+
+// The roles are separate (noinline) functions so that each gets the whole register file.  They read the launch arguments
+// from the kernel-argument segment (scalar loads: every field stays wave-uniform); the kernel hands them its address
+// (the intrinsic itself folds to null inside a callee) and the callee makes it provably uniform again.
+typedef const __attribute__((address_space(4))) wa_mega_args * mg_kargs;
+__device__ __forceinline__ mg_kargs mg_uniform(mg_kargs p) {
+    const unsigned long long v = (unsigned long long) p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+    return (mg_kargs) (((unsigned long long) hi << 32) | lo);
+}
+
+#define MG_THREADS 512
+#define MG_NW (MG_THREADS / 64)
+#define MG_NPL 20                 // LayerNorm elements per lane of one wave: d <= 1280
+#define MG_SPIN_LIMIT 300000u     // polls (~0.5 us each) before a hand-off is declared dead
+
+enum { E_QKV = 0, E_AO, E_X1, E_QC, E_AO2, E_X2, E_HF, E_X3 };
+
+struct mg_ctl { gu32 * status; unsigned seq; bool dead; };
+
+__device__ __forceinline__ void gr_store(gu64 * g, unsigned seq, unsigned v) {
+    __hip_atomic_store(g, ((u64) seq << 32) | (u64) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gr_load(gu64 * g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xf, 0xf, true); }
+
+__device__ __forceinline__ gu64 * mg_edge(mg_kargs A, int layer, int e) {
+    return (gu64 *) A->granules + ((size_t) layer * WA_MEGA_EDGES + e) * A->edge_stride;
+}
+
+// One wave polls the granules idx(0..NPL-1) (idx < 0: none) until every tag equals this launch's sequence number.
+template <int NPL, typename F>
+__device__ __forceinline__ void mg_sweep(gu64 * g, F idx, mg_ctl & c, int lane, unsigned (&v)[NPL], unsigned code) {
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int i = idx(k);
+            if (i >= 0) { const u64 x = gr_load(g + i); v[k] = (unsigned) x; ok &= (unsigned) (x >> 32) == c.seq; }
+        }
+        if (__all(ok) || c.dead) return;
+        if ((spins & 127u) == 127u) {
+            const unsigned st = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (st != 0u) { c.dead = true; return; }
+            if (spins >= MG_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(c.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c.dead = true;
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// wave 0 of a workgroup: obtain the F32 residual row (from granules, or from the embeddings for layer 0), keep it in
+// LDS (xf) and write LayerNorm(row) as F16 into xin.  ops.cpp:3225-3242 semantics, as k_layernorm_exact.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge /* null: embeddings */, gcf lw, gcf lb, int lane, float * xf,
+                                             wa_f16 * xin, unsigned code) {
+    const int d = A->d;
+    float xv[MG_NPL], gw[MG_NPL], gb[MG_NPL];
+#pragma unroll
+    for (int k = 0; k < MG_NPL; ++k) {            // gamma / beta do not depend on the hand-off: in flight while polling
+        const int i = lane + 64 * k;
+        const bool ok = i < d;
+        gw[k] = ok ? lw[i] : 0.0f; gb[k] = ok ? lb[i] : 0.0f;
+    }
+    if (edge) {
+        unsigned v[MG_NPL];
+        mg_sweep<MG_NPL>(edge, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
+#pragma unroll
+        for (int k = 0; k < MG_NPL; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
+    } else {                                      // k_dec_embed: token embedding + positional embedding
+        const gch te = (gch) A->te + (size_t) A->token * d;
+        const gcf pe = (gcf) A->pe + (size_t) A->pos * d;
+#pragma unroll
+        for (int k = 0; k < MG_NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? h2f(te[i]) + pe[i] : 0.0f; }
+    }
+#pragma unroll
+    for (int k = 0; k < MG_NPL; ++k) { const int i = lane + 64 * k; if (i < d) xf[i] = xv[k]; }
+    double s = 0.0, a = 0.0;
+#pragma unroll
+    for (int k = 0; k < MG_NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
+    s = wave_sum_d(s); a = wave_sum_d(a);
+    float mean;
+    if (!wa_sum_certain(s, a, d, mean)) {
+        if (lane == 0) s = wa_seq_sum_lds(xf, d, false, 0.0f);
+        s = __shfl(s, 0, WAVE);
+        mean = (float) (s / (double) d);
+    }
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < MG_NPL; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
+    s2 = wave_sum_d(s2);
+    float variance;
+    if (!wa_sum_certain(s2, s2, d, variance)) {
+        if (lane == 0) s2 = wa_seq_sum_lds(xf, d, true, mean);
+        s2 = __shfl(s2, 0, WAVE);
+        variance = (float) (s2 / (double) d);
+    }
+    const float scale = 1.0f / sqrtf(variance + A->eps);
+#pragma unroll
+    for (int k = 0; k < MG_NPL; ++k) {
+        const int i = lane + 64 * k;
+        if (i < d) {
+            float y = xv[k] - mean;
+            y = y * scale;
+            y = y * gw[k];
+            y = y + gb[k];
+            xin[i] = f2h(y);
+        }
+    }
+}
+
+// wave(s): copy the packed-F16 granules [i0, i1) (two halfs each) into LDS once they are all valid
+template <int NPL>
+__device__ __forceinline__ void mg_gather_h2(mg_ctl & c, gu64 * edge, int i0, int i1, int lane, unsigned * dst32, unsigned code) {
+    unsigned v[NPL];
+    mg_sweep<NPL>(edge, [&](int k) { const int i = i0 + lane + 64 * k; return i < i1 ? i : -1; }, c, lane, v, code);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { const int i = i0 + lane + 64 * k; if (i < i1) dst32[i] = v[k]; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// GEMV rows in ggml_vec_dot_f16 order (as k_gemv_exact).  pf[] holds the weights of the first <= 48 (LPR 8) or
+// <= 96 (LPR 16) 32-element steps of a lane's row, loaded ahead of the hand-off.
+//   LPR 8 : lane u owns elements 4u..4u+3 of every step (8-byte loads);  result in lanes with u == 0
+//   LPR 16: lane u owns elements 2u, 2u+1 (4-byte loads; long rows, few of them); result in lanes with u == 0
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mg_pf8(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, int s0) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+        if (s0 + 4 * c < nsteps) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int b = 4 * c + bb;
+                if (valid) { const u32x2 t = *(const GAS u32x2 *) (wrow + (size_t) (s0 + b) * 32); pf[2 * b] = t.x; pf[2 * b + 1] = t.y; }
+            }
+        }
+    }
+}
+__device__ __forceinline__ float mg_dot8(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, const wa_f16 * xin, int u, bool have_first) {
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int s0 = 0; s0 < nsteps; s0 += 48) {
+        if (s0 > 0 || !have_first) mg_pf8(pf, wrow, valid, nsteps, s0);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            if (s0 + 4 * c < nsteps) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const int b = 4 * c + bb;
+                    u32x2 t; t.x = pf[2 * b]; t.y = pf[2 * b + 1];
+                    const half4v w4 = __builtin_bit_cast(half4v, t);
+                    const half4v x4 = *(const half4v *) (xin + (size_t) (s0 + b) * 32 + 4 * u);
+                    acc[0] = fmaf((float) w4[0], (float) x4[0], acc[0]);
+                    acc[1] = fmaf((float) w4[1], (float) x4[1], acc[1]);
+                    acc[2] = fmaf((float) w4[2], (float) x4[2], acc[2]);
+                    acc[3] = fmaf((float) w4[3], (float) x4[3], acc[3]);
+                }
+            }
+        }
+    }
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = acc[i];
+        v = v + dpp_f32<0x104>(v);          // row_shl:4  s[j] + s[j+2]
+        v = v + dpp_f32<0x102>(v);          // row_shl:2  (s0+s2) + (s1+s3)
+        t[i] = v + dpp_f32<0x101>(v);       // row_shl:1  a[l] + a[l+4]
+    }
+    return (t[0] + t[1]) + (t[2] + t[3]);
+}
+__device__ __forceinline__ void mg_pf16(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, int s0) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+        if (s0 + 8 * c < nsteps) {
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                const int b = 8 * c + bb;
+                if (valid) pf[b] = *(const GAS unsigned *) (wrow + (size_t) (s0 + b) * 32);
+            }
+        }
+    }
+}
+__device__ __forceinline__ float mg_dot16(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, const wa_f16 * xin, int u, bool have_first) {
+    float acc[2] = { 0.0f, 0.0f };
+    for (int s0 = 0; s0 < nsteps; s0 += 96) {
+        if (s0 > 0 || !have_first) mg_pf16(pf, wrow, valid, nsteps, s0);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            if (s0 + 8 * c < nsteps) {
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const int b = 8 * c + bb;
+                    const half2v w2 = __builtin_bit_cast(half2v, pf[b]);
+                    const half2v x2 = *(const half2v *) (xin + (size_t) (s0 + b) * 32 + 2 * u);
+                    acc[0] = fmaf((float) w2[0], (float) x2[0], acc[0]);
+                    acc[1] = fmaf((float) w2[1], (float) x2[1], acc[1]);
+                }
+            }
+        }
+    }
+    float t[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v = acc[i];
+        v = v + dpp_f32<0x108>(v);          // row_shl:8  s[j] + s[j+2]
+        v = v + dpp_f32<0x104>(v);          // row_shl:4  (s0+s2) + (s1+s3)
+        t[i] = v + dpp_f32<0x102>(v);       // row_shl:2  a[l] + a[l+4]   -> lane 0: t0,t1  lane 1: t2,t3
+    }
+    const float r = t[0] + t[1];
+    return r + dpp_f32<0x101>(r);           // (t0+t1) + (t2+t3)
+}
+
+// rows of one matrix owned by one GEMV workgroup: an even count, the same for every workgroup
+__device__ __forceinline__ int mg_rpw(int N, int nG) { const int r = (N + nG - 1) / nG; return (r + 1) & ~1; }
+
+struct mg_task { gch wrow; bool valid; int row; float bias, scale; };
+
+__device__ __forceinline__ mg_task mg_task8(unsigned (&pf)[96], const wa_f16 * W, const float * bias, const float * scale, int N, int K,
+                                            int row0, int rows_wg, int grp, int lane) {
+    mg_task t;
+    const int ri = grp * 8 + (lane >> 3);
+    t.row = row0 + ri;
+    t.valid = ri < rows_wg && t.row < N;
+    t.wrow = (gch) W + (size_t) (t.valid ? t.row : 0) * K + 4 * (lane & 7);
+    t.bias = 0.0f; t.scale = 1.0f;
+    mg_pf8(pf, t.wrow, t.valid, K >> 5, 0);
+    if (t.valid && (lane & 7) == 0) { if (bias) t.bias = ((gcf) bias)[t.row]; if (scale) t.scale = ((gcf) scale)[t.row]; }
+    return t;
+}
+__device__ __forceinline__ mg_task mg_task16(unsigned (&pf)[96], const wa_f16 * W, const float * bias, int N, int K, int row0, int rows_wg,
+                                             int grp, int lane) {
+    mg_task t;
+    const int ri = grp * 4 + (lane >> 4);
+    t.row = row0 + ri;
+    t.valid = ri < rows_wg && t.row < N;
+    t.wrow = (gch) W + (size_t) (t.valid ? t.row : 0) * K + 2 * (lane & 15);
+    t.bias = 0.0f; t.scale = 1.0f;
+    mg_pf16(pf, t.wrow, t.valid, K >> 5, 0);
+    if (t.valid && (lane & 15) == 0 && bias) t.bias = ((gcf) bias)[t.row];
+    return t;
+}
+
+// publish two F16 results (rows n, n+1 of lanes 16j and 16j+8) as one granule; returns the packed pair in lanes 16j
+__device__ __forceinline__ unsigned mg_pub_h2(gu64 * edge, unsigned seq, bool valid, int n, unsigned h, int lane) {
+    const unsigned hi = dpp_u32<0x108>(h);
+    const unsigned pk = (h & 0xffffu) | (hi << 16);
+    if (valid && (lane & 15) == 0) gr_store(edge + (n >> 1), seq, pk);
+    return pk;
+}
+
+// -------------------------------------------------------------------------------------------------
+// final LayerNorm + logits = token_embedding . x (whisper.cpp:2820-2835): every workgroup, every wave
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mg_prefetch_logits(mg_kargs A, unsigned (&pf)[96], bool & have_pf, int lane, int wave) {
+    const int g = (int) blockIdx.x + (int) gridDim.x * wave;
+    const int row = g * 8 + (lane >> 3);
+    const bool valid = row < A->n_vocab;
+    mg_pf8(pf, (gch) A->te + (size_t) (valid ? row : 0) * A->d + 4 * (lane & 7), valid, A->d >> 5, 0);
+    have_pf = true;
+}
+__device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char * smem, unsigned (&pf)[96], bool have_pf, int lane, int wave) {
+    float  * xf  = (float *) smem;
+    wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);
+    const int d = A->d, nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab;
+    if (wave == 0) mg_gather_ln(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, (gcf) A->lnf_w, (gcf) A->lnf_b, lane, xf, xin, 3000u);
+    __syncthreads();
+    const int NG = (n_vocab + 7) >> 3;
+    GAS float * logits = (GAS float *) A->logits;
+    for (int j = 0;; ++j) {
+        const int g = wg + nwg * (wave + MG_NW * j);
+        if (g >= NG) break;
+        const int row = g * 8 + (lane >> 3);
+        const bool valid = row < n_vocab;
+        const gch wrow = (gch) A->te + (size_t) (valid ? row : 0) * d + 4 * (lane & 7);
+        const float r = mg_dot8(pf, wrow, valid, d >> 5, xin, lane & 7, j == 0 && have_pf);
+        if (valid && (lane & 7) == 0) logits[row] = r;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// role: GEMV workgroup.  wave 0 gathers (and normalises) the input of every phase; waves 1,2 own the QKV and FC1 rows,
+// wave 3 the two out-projections, wave 4 the cross query, wave 5 FC2; waves 6,7 help gather the 4d-wide FC2 input.
+// Every wave loads the weights of its NEXT task right after finishing the current one.
+// -------------------------------------------------------------------------------------------------
+__device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const mg_kargs A = mg_uniform(A_);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = blockIdx.x, nG = (int) gridDim.x - 2 * A->n_head;
+    mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+    unsigned pf[96];
+    bool have_pf = false;
+
+    float  * xf  = (float *) smem;                               // [d]   residual row (F32)
+    wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);        // [4d]  GEMV input (F16)
+    const int d = A->d, L = A->n_layer, d4 = 4 * d;
+    const int r_qkv = mg_rpw(3 * d, nG), r_d = mg_rpw(d, nG), r_ff = mg_rpw(d4, nG);
+    const int row_qkv = wg * r_qkv, row_d = wg * r_d, row_ff = wg * r_ff;
+    const int g_qkv = (r_qkv + 7) >> 3, g_ff = (r_ff + 7) >> 3, g_d8 = (r_d + 7) >> 3, g_d16 = (r_d + 3) >> 2;
+    const GAS wa_mega_layer * Ly = (const GAS wa_mega_layer *) A->layers;
+    const unsigned seq = c.seq;
+    const int hf_seg = (((2 * d + 2) / 3 + 63) >> 6) << 6;      // FC2-input granules swept by each of the waves 0, 6, 7
+    const int kv_head = A->kv_head;
+
+    mg_task t; t.valid = false; t.row = 0; t.wrow = nullptr; t.bias = 0.f; t.scale = 1.f;
+    if (wave == 1 || wave == 2) t = mg_task8(pf, Ly[0].qkv_w, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+    else if (wave == 3)         t = mg_task8(pf, Ly[0].out_w, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+    else if (wave == 4)         t = mg_task8(pf, Ly[0].cq_w, Ly[0].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+    else if (wave == 5)         t = mg_task16(pf, Ly[0].fc2_w, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
+    else if (wave >= 6)         mg_prefetch_logits(A, pf, have_pf, lane, wave);      // held until the final phase
+
+    for (int l = 0; l < L; ++l) {
+        const GAS wa_mega_layer & Y = Ly[l];
+        // ---------------- P1: LayerNorm + q|k|v ----------------
+        if (wave == 0) mg_gather_ln(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), (gcf) Y.ln1_w, (gcf) Y.ln1_b, lane, xf, xin, 100u + l);
+        __syncthreads();
+        if (wave == 1 || wave == 2) {
+            gu64 * eq = mg_edge(A, l, E_QKV);
+            for (int grp = wave - 1; grp < g_qkv; grp += 2) {
+                if (grp >= 2) t = mg_task8(pf, Y.qkv_w, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane);
+                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                v = v + t.bias;
+                v = v * t.scale;
+                const unsigned pk = mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
+                if (t.valid && (lane & 15) == 0 && t.row >= d) {      // new key / value also go to their KV cell for later tokens
+                    GAS wa_f16 * cell = (t.row < 2 * d ? (GAS wa_f16 *) A->kv_k + (t.row - d) : (GAS wa_f16 *) A->kv_v + (t.row - 2 * d)) +
+                                        (size_t) l * A->kv_layer_stride + (size_t) kv_head * d;
+                    *(GAS unsigned *) cell = pk;
+                }
+            }
+            t = mg_task8(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+        }
+        // ---------------- P3: self-attention out-projection + residual ----------------
+        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO), 0, d >> 1, lane, (unsigned *) xin, 200u + l);
+        __syncthreads();
+        if (wave == 3) {
+            gu64 * ex = mg_edge(A, l, E_X1);
+            for (int grp = 0; grp < g_d8; ++grp) {
+                if (grp >= 1) t = mg_task8(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane);
+                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                v = v + t.bias;
+                if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
+            }
+            t = mg_task8(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+        }
+        // ---------------- P4: LayerNorm + cross query ----------------
+        if (wave == 0) mg_gather_ln(A, c, mg_edge(A, l, E_X1), (gcf) Y.ln2_w, (gcf) Y.ln2_b, lane, xf, xin, 300u + l);
+        __syncthreads();
+        if (wave == 4) {
+            gu64 * eq = mg_edge(A, l, E_QC);
+            for (int grp = 0; grp < g_d8; ++grp) {
+                if (grp >= 1) t = mg_task8(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane);
+                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                v = v + t.bias;
+                mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
+            }
+            if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+        }
+        // ---------------- P6: cross-attention out-projection + residual ----------------
+        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO2), 0, d >> 1, lane, (unsigned *) xin, 400u + l);
+        __syncthreads();
+        if (wave == 3) {
+            gu64 * ex = mg_edge(A, l, E_X2);
+            for (int grp = 0; grp < g_d8; ++grp) {
+                if (grp >= 1) t = mg_task8(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane);
+                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                v = v + t.bias;
+                if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
+            }
+            if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+        }
+        // ---------------- P7: LayerNorm + FC1 + GELU ----------------
+        if (wave == 0) mg_gather_ln(A, c, mg_edge(A, l, E_X2), (gcf) Y.ln3_w, (gcf) Y.ln3_b, lane, xf, xin, 500u + l);
+        __syncthreads();
+        if (wave == 1 || wave == 2) {
+            gu64 * eh = mg_edge(A, l, E_HF);
+            const gch gelu = (gch) A->gelu;
+            for (int grp = wave - 1; grp < g_ff; grp += 2) {
+                if (grp >= 2) t = mg_task8(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane);
+                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                v = v + t.bias;
+                float gl = v;                                      // wa_gelu (vec.h:571-585) through the global F16 table
+                if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu[t.valid ? f2h(v) : 0]);
+                mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
+            }
+            if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+        }
+        // ---------------- P8: FC2 + residual ----------------
+        if (wave == 0 || wave >= 6) {
+            const int gi = wave == 0 ? 0 : wave - 5;
+            const int i0 = gi * hf_seg, i1 = min(2 * d, i0 + hf_seg);
+            mg_gather_h2<(((2 * WA_MEGA_MAX_D + 2) / 3 + 63) / 64)>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l);
+        }
+        __syncthreads();
+        if (wave == 5) {
+            gu64 * ex = mg_edge(A, l, E_X3);
+            for (int grp = 0; grp < g_d16; ++grp) {
+                if (grp >= 1) t = mg_task16(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, grp, lane);
+                float v = mg_dot16(pf, t.wrow, t.valid, d4 >> 5, xin, lane & 15, true);
+                v = v + t.bias;
+                if (t.valid && (lane & 15) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
+            }
+            if (l + 1 < L) t = mg_task16(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
+        }
+    }
+    if (wave >= 1 && wave <= 5) mg_prefetch_logits(A, pf, have_pf, lane, wave);
+    mg_final(A, c, smem, pf, have_pf, lane, wave);
+}
+
+// -------------------------------------------------------------------------------------------------
+// soft_max over sc[0..n) exactly as ops.cpp:4792-4818 + vec.cpp:257-308 (k_attn_exact); leaves F16 probabilities in p16
+// -------------------------------------------------------------------------------------------------
+struct mg_att_smem { float * sc; wa_f16 * p16; float * gs; float * red; double * redd; float * s_inv; wa_f16 * qs; float * part; };
+__device__ __forceinline__ mg_att_smem mg_att_carve(unsigned char * base, int maxkv) {
+    mg_att_smem m;
+    m.redd = (double *) base;                       base += 8 * sizeof(double);
+    m.sc   = (float *) base;                        base += (size_t) maxkv * 4;
+    m.gs   = (float *) base;                        base += (size_t) (maxkv / 8) * 4;
+    m.part = (float *) base;                        base += 32 * 64 * 4;
+    m.red  = (float *) base;                        base += 8 * 4;
+    m.s_inv = (float *) base;                       base += 4 * 4;
+    m.p16  = (wa_f16 *) base;                       base += (size_t) maxkv * 2;
+    m.qs   = (wa_f16 *) base;
+    return m;
+}
+#define MG_ATT_SMEM(maxkv) (8 * 8 + (maxkv) * 4 + ((maxkv) / 8) * 4 + 32 * 64 * 4 + 8 * 4 + 16 + (maxkv) * 2 + 64 * 2 + 64)
+
+__device__ __forceinline__ void mg_softmax(const mg_att_smem & M, int n_kv, float lmax, int tid, int lane, int wave, GAS float * dbg = nullptr) {
+    float * sc = M.sc;
+    lmax = wave_max(lmax);
+    if (lane == 0) M.red[wave] = lmax;
+    __syncthreads();
+    float mx = M.red[0];
+#pragma unroll
+    for (int w = 1; w < MG_NW; ++w) mx = fmaxf(mx, M.red[w]);
+    const int n8 = n_kv & ~7;
+    if (dbg) for (int cc = tid; cc < n_kv; cc += MG_THREADS) dbg[cc] = sc[cc];
+    for (int cc = tid; cc < n_kv; cc += MG_THREADS) sc[cc] = cc < n8 ? wa_expf(sc[cc] - mx) : wa_expf_libm(sc[cc] - mx);
+    __syncthreads();
+    for (int g = tid; g < (n8 >> 3); g += MG_THREADS) {
+        const float * v = &sc[g * 8];
+        M.gs[g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+    }
+    __syncthreads();
+    {
+        double ps = 0.0;
+        const int ng = n8 >> 3;
+        for (int g = tid; g < ng; g += MG_THREADS) ps += (double) M.gs[g];
+        for (int cc = n8 + tid; cc < n_kv; cc += MG_THREADS) ps += (double) sc[cc];
+        ps = wave_sum_d(ps);
+        if (lane == 0) M.redd[wave] = ps;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < MG_NW; ++w) sum += M.redd[w];
+            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
+            const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
+            if (ilo != ihi) {
+                sum = 0.0;
+                for (int g = 0; g < ng; ++g) sum += (double) M.gs[g];
+                for (int cc = n8; cc < n_kv; ++cc) sum += (double) sc[cc];
+                *M.s_inv = (float) (1.0 / sum);
+            } else *M.s_inv = ilo;
+        }
+        __syncthreads();
+    }
+    const float inv = *M.s_inv;
+    for (int cc = tid; cc < n_kv; cc += MG_THREADS) { M.p16[cc] = f2h(sc[cc] * inv); if (dbg) dbg[1536 + cc] = sc[cc] * inv; }
+    __syncthreads();
+}
+
+// one key's score from its two 16-byte pieces (lane a of the key's 4-lane group): k_attn_exact's arithmetic
+__device__ __forceinline__ float mg_score(const u32x4 & ka, const u32x4 & kb, const float (&qa)[8], const float (&qb)[8], float scale) {
+    const wa_f16 * k8a = (const wa_f16 *) &ka, * k8b = (const wa_f16 *) &kb;
+    float v[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        float t = fmaf(h2f(k8a[l]), qa[l], 0.0f);
+        t = fmaf(h2f(k8b[l]), qb[l], t);
+        t = t + dpp_f32<0x4e>(t);                // quad_perm [2,3,0,1]: s[j] + s[j+2]
+        v[l] = t + dpp_f32<0xb1>(t);             // quad_perm [1,0,3,2]: (s0+s2) + (s1+s3)
+    }
+    const float t0 = v[0] + v[4], t1 = v[1] + v[5], t2 = v[2] + v[6], t3 = v[3] + v[7];
+    return ((t0 + t1) + (t2 + t3)) * scale;
+}
+
+// final tree over the 32 partial-sum chains + F64 leftovers, by threads 0..63 (tid = d_head index); then publish
+__device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 * vleft /* [nl][64] */, const wa_f16 * p16, int np, int nl,
+                                               gu64 * edge, int h, unsigned seq, int tid) {
+    if (tid < 64) {
+        float s32[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
+        double sumf = (double) wa_tree32(s32);
+        float prod[32];
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) {
+            const int c2 = cc < nl ? cc : 0;
+            prod[cc] = h2f(vleft[c2 * 64 + tid]) * h2f(p16[np + c2]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) if (cc < nl) sumf += (double) prod[cc];
+        const unsigned hv = (unsigned) f2h((float) sumf);
+        const unsigned hi = dpp_u32<0x101>(hv);          // row_shl:1: lane i reads lane i+1
+        if ((tid & 1) == 0) gr_store(edge + ((h * 64 + tid) >> 1), seq, (hv & 0xffffu) | (hi << 16));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// role: self-attention of head h (whisper.cpp:2636-2651), every layer.  The K/V cells of earlier tokens are copied
+// into LDS while the GEMV workgroups are busy with the previous phases; the new cell arrives with the query.
+// -------------------------------------------------------------------------------------------------
+__device__ __noinline__ void mg_role_self(mg_kargs A_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const mg_kargs A = mg_uniform(A_);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = (int) blockIdx.x - ((int) gridDim.x - 2 * A->n_head);
+    mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+
+    wa_f16 * Ks = (wa_f16 *) smem;                                  // [512][64]
+    wa_f16 * Vs = Ks + WA_MEGA_MAX_KV * 64;                          // [512][64]
+    const mg_att_smem M = mg_att_carve(smem + (size_t) WA_MEGA_MAX_KV * 64 * 2 * 2, WA_MEGA_MAX_KV);
+    const int d = A->d, n_kv = A->n_kv, kv_head = A->kv_head, L = A->n_layer;
+    const int a = tid & 3, kslot = tid >> 2;
+    for (int l = 0; l < L; ++l) {
+        {   // cells of earlier tokens -> LDS (row kv_head is stale here and replaced below)
+            const gch kc = (gch) A->kv_k + (size_t) l * A->kv_layer_stride + h * 64;
+            const gch vc = (gch) A->kv_v + (size_t) l * A->kv_layer_stride + h * 64;
+            const int n16 = n_kv * 8;
+            u32x4 tk[8], tv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + MG_THREADS * j;
+                if (idx < n16) {
+                    tk[j] = *(const GAS u32x4 *) (kc + (size_t) (idx >> 3) * d + (idx & 7) * 8);
+                    tv[j] = *(const GAS u32x4 *) (vc + (size_t) (idx >> 3) * d + (idx & 7) * 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + MG_THREADS * j;
+                if (idx < n16) { *(u32x4 *) (Ks + (size_t) idx * 8) = tk[j]; *(u32x4 *) (Vs + (size_t) idx * 8) = tv[j]; }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {    // q | k | v of this head: three runs of 32 packed granules
+            unsigned v[2];
+            mg_sweep<2>(mg_edge(A, l, E_QKV), [&](int k) {
+                if (k == 0) return (lane < 32 ? 0 : (d >> 1)) + h * 32 + (lane & 31);
+                return lane < 32 ? d + h * 32 + lane : -1; }, c, lane, v, 1000u + l);
+            if (lane < 32) { ((unsigned *) M.qs)[lane] = v[0]; ((unsigned *) (Vs + (size_t) kv_head * 64))[lane] = v[1]; }
+            else ((unsigned *) (Ks + (size_t) kv_head * 64))[lane - 32] = v[0];
+        }
+        __syncthreads();
+        // ---- scores: 4 lanes per key ----
+        float lmax = -INFINITY;
+        {
+            float qa[8], qb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { qa[i] = h2f(M.qs[8 * a + i]); qb[i] = h2f(M.qs[32 + 8 * a + i]); }
+            for (int c0 = 0; c0 < n_kv; c0 += MG_THREADS / 4) {
+                const int cc = c0 + kslot, cl = cc < n_kv ? cc : n_kv - 1;
+                const u32x4 ka = *(const u32x4 *) (Ks + (size_t) cl * 64 + 8 * a), kb = *(const u32x4 *) (Ks + (size_t) cl * 64 + 32 + 8 * a);
+                const float r = mg_score(ka, kb, qa, qb, 1.0f);
+                if (cc < n_kv) { if (a == 0) M.sc[cc] = r; lmax = fmaxf(lmax, r); }
+            }
+        }
+        mg_softmax(M, n_kv, lmax, tid, lane, wave);
+        // ---- P V: chains r = cell mod 32 (4 per wave), lane = d_head index ----
+        const int np = n_kv & ~31, nsteps = np >> 5;
+        {
+            float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const int r0 = wave * 4;
+            for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i] = fmaf(h2f(Vs[(size_t) (s * 32 + r0 + i) * 64 + lane]), h2f(M.p16[s * 32 + r0 + i]), acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) M.part[(r0 + i) * 64 + lane] = acc[i];
+        }
+        __syncthreads();
+        mg_attn_finish(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid);
+        __syncthreads();
+    }
+    unsigned pf[96];
+    bool have_pf = false;
+    if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
+    mg_final(A, c, smem, pf, have_pf, lane, wave);
+}
+
+// -------------------------------------------------------------------------------------------------
+// role: cross-attention of head h over the encoder K/V (whisper.cpp:2683-2758), every layer.  One workgroup holds the
+// whole head on chip: the first 1024 keys in LDS, the rest of K as 2 x 16 bytes per (key, lane-of-4) in registers, V as
+// the 2 x 47 packed pairs of each half-wave's two partial-sum chains in registers; everything is loaded right after the
+// previous layer's result has been published, i.e. a whole layer ahead of the query that needs it.
+// -------------------------------------------------------------------------------------------------
+#define MG_CK_LDS 1024                                  // keys of the head kept in LDS
+#define MG_CPASS_R ((WA_MEGA_MAX_T - MG_CK_LDS) / 128)  // register passes of 128 keys behind them
+#define MG_CSTEPS 47
+
+__device__ __noinline__ void mg_role_cross(mg_kargs A_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const mg_kargs A = mg_uniform(A_);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = (int) blockIdx.x - ((int) gridDim.x - A->n_head);
+    mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+
+    wa_f16 * Kl = (wa_f16 *) smem;                                   // [1024][64]
+    wa_f16 * vleft = Kl + (size_t) MG_CK_LDS * 64;                   // [32][64]
+    const mg_att_smem M = mg_att_carve(smem + (size_t) MG_CK_LDS * 64 * 2 + 32 * 64 * 2, WA_MEGA_MAX_T);
+    const int T = A->T, tpad = A->cross_tpad, L = A->n_layer;
+    const float kq_scale = A->kq_scale;
+    const int a = tid & 3, kslot = tid >> 2;
+    const int np = T & ~31, nsteps = np >> 5, nl = T - np;
+    const int hw = lane >> 5, l2 = lane & 31;
+    const int n_lds = T < MG_CK_LDS ? T : MG_CK_LDS;
+    for (int l = 0; l < L; ++l) {
+        const gch kp = (gch) A->cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
+        const gch vp = (gch) A->cross_v + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
+        u32x4 ka[MG_CPASS_R], kb[MG_CPASS_R];
+        unsigned vv[2][MG_CSTEPS];
+#pragma unroll
+        for (int b = 0; b < MG_CPASS_R; ++b) {
+            const int cc = MG_CK_LDS + b * 128 + kslot;
+            if (cc < tpad && MG_CK_LDS + b * 128 < T) {
+                ka[b] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 8 * a); kb[b] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 32 + 8 * a);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < MG_CSTEPS; ++s) {
+            if (s < nsteps) {
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) vv[ci][s] = *(const GAS unsigned *) (vp + (size_t) (s * 32 + wave * 4 + hw * 2 + ci) * 64 + 2 * l2);
+            }
+        }
+        {   // keys [0, n_lds) -> LDS, 16 bytes per thread per pass
+            const int n16 = n_lds * 8;
+#pragma unroll
+            for (int j0 = 0; j0 < 16; j0 += 8) {
+                u32x4 tk[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int idx = tid + MG_THREADS * (j0 + j); if (idx < n16) tk[j] = *(const GAS u32x4 *) (kp + (size_t) idx * 8); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int idx = tid + MG_THREADS * (j0 + j); if (idx < n16) *(u32x4 *) (Kl + (size_t) idx * 8) = tk[j]; }
+            }
+        }
+        if (tid < 256) {       // the T % 32 leftover rows of V
+            const int row = tid >> 3;
+            if (row < nl) *(u32x4 *) (vleft + (size_t) tid * 8) = *(const GAS u32x4 *) (vp + (size_t) (np + row) * 64 + (tid & 7) * 8);
+        }
+        if (wave == 0) {
+            unsigned v[1];
+            mg_sweep<1>(mg_edge(A, l, E_QC), [&](int) { return lane < 32 ? h * 32 + lane : -1; }, c, lane, v, 2000u + l);
+            if (lane < 32) ((unsigned *) M.qs)[lane] = v[0];
+        }
+        __syncthreads();
+        float lmax = -INFINITY;
+        {
+            float qa[8], qb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { qa[i] = h2f(M.qs[8 * a + i]); qb[i] = h2f(M.qs[32 + 8 * a + i]); }
+            for (int c0 = 0; c0 < n_lds; c0 += 128) {
+                const int cc = c0 + kslot, cl = cc < n_lds ? cc : n_lds - 1;
+                const u32x4 k0 = *(const u32x4 *) (Kl + (size_t) cl * 64 + 8 * a), k1 = *(const u32x4 *) (Kl + (size_t) cl * 64 + 32 + 8 * a);
+                const float r = mg_score(k0, k1, qa, qb, kq_scale);
+                if (cc < n_lds) { if (a == 0) M.sc[cc] = r; lmax = fmaxf(lmax, r); }
+            }
+#pragma unroll
+            for (int b = 0; b < MG_CPASS_R; ++b) {
+                if (MG_CK_LDS + b * 128 < T) {
+                    const int cc = MG_CK_LDS + b * 128 + kslot;
+                    const float r = mg_score(ka[b], kb[b], qa, qb, kq_scale);
+                    if (cc < T) { if (a == 0) M.sc[cc] = r; lmax = fmaxf(lmax, r); }
+                }
+            }
+        }
+        mg_softmax(M, T, lmax, tid, lane, wave, A->dbg ? (GAS float *) A->dbg + ((size_t) l * A->n_head + h) * 5120 : nullptr);
+        {
+            float acc[2][2] = { { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+#pragma unroll
+            for (int s = 0; s < MG_CSTEPS; ++s) {
+                if (s < nsteps) {
+#pragma unroll
+                    for (int ci = 0; ci < 2; ++ci) {
+                        const float p = h2f(M.p16[s * 32 + wave * 4 + hw * 2 + ci]);
+                        const half2v v2 = __builtin_bit_cast(half2v, vv[ci][s]);
+                        acc[ci][0] = fmaf((float) v2[0], p, acc[ci][0]);
+                        acc[ci][1] = fmaf((float) v2[1], p, acc[ci][1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                M.part[(wave * 4 + hw * 2 + ci) * 64 + 2 * l2]     = acc[ci][0];
+                M.part[(wave * 4 + hw * 2 + ci) * 64 + 2 * l2 + 1] = acc[ci][1];
+            }
+        }
+        __syncthreads();
+        if (A->dbg) for (int i = tid; i < 2048; i += MG_THREADS) ((GAS float *) A->dbg)[((size_t) l * A->n_head + h) * 5120 + 3072 + i] = M.part[i];
+        mg_attn_finish(M.part, vleft, M.p16, np, nl, mg_edge(A, l, E_AO2), h, c.seq, tid);
+        __syncthreads();
+    }
+    unsigned pf[96];
+    bool have_pf = false;
+    if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
+    mg_final(A, c, smem, pf, have_pf, lane, wave);
+}
+
+__global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A) {
+    const int nG = (int) gridDim.x - 2 * A.n_head;
+    const int wg = blockIdx.x;
+    const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();     // = &A (the struct is the only argument)
+    if (wg < nG)                 mg_role_gemv(Ap);
+    else if (wg < nG + A.n_head) mg_role_self(Ap);
+    else                         mg_role_cross(Ap);
+}
+
+size_t wa_mega_lds_bytes() {
+    const size_t s_self  = (size_t) WA_MEGA_MAX_KV * 64 * 2 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_KV);
+    const size_t s_cross = (size_t) MG_CK_LDS * 64 * 2 + 32 * 64 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_T);
+    const size_t s_gemv  = (size_t) WA_MEGA_MAX_D * 4 + (size_t) 4 * WA_MEGA_MAX_D * 2;
+    size_t m = s_self > s_cross ? s_self : s_cross;
+    m = m > s_gemv ? m : s_gemv;
+    return (m + 255) & ~(size_t) 255;
+}
+
+void wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg) {
+    static bool attr_set = false;
+    const size_t lds = wa_mega_lds_bytes();
+    if (!attr_set) {
+        (void) hipFuncSetAttribute((const void *) k_decode_mega, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_decode_mega, dim3(n_wg), dim3(MG_THREADS), lds, s, a);
+}
