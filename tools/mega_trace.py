@@ -1,0 +1,31 @@
+"""Timeline of the one-launch decode step: per phase, when one workgroup of each role saw its input / published."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "whisper-rust_amd"))
+import numpy as np
+import wsynth, whisper_rs as W
+os.environ["WHISPER_AMD_MEGA_DBG"] = "1"
+name = sys.argv[1] if len(sys.argv) > 1 else "small"
+n_past = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
+ctx = W.WhisperContext.new_with_params(wsynth.model_path(name), W.WhisperContextParameters(lib), lib=lib)
+st = ctx.create_state()
+st.pcm_to_mel(wsynth.synth_audio(480000, 0)); st.encode(0)
+L, d, nv, H = ctx.model_n_text_layer(), ctx.model_n_text_state(), ctx.n_vocab(), ctx.model_n_text_head()
+lib.whisper_amd_mega_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+g = np.zeros(L * 8 * 2 * d, dtype=np.uint64); lg = np.zeros(nv, dtype=np.float32)
+for it in range(3):
+    rc = lib.whisper_amd_mega_debug(ctx.ptr, st.ptr, 1000, n_past, g.ctypes.data, lg.ctypes.data)
+tr = np.fromfile("gpurun_out/mega_dbg.bin", dtype=np.uint32)[L * H * 5120:].reshape(-1, 8)
+names = ["P1 ln+qkv", "P3 out", "P4 ln+cq", "P6 cout", "P7 ln+fc1", "P8 fc2", "S  self", "C  cross"]
+t0 = int(tr[0, 2])            # layer 0 P1: LayerNorm of the embeddings done
+us = lambda t: (int(t) - t0) / 100.0
+print("rc", rc, " times in us since layer-0 LN ready; [input seen (polls)] [lds ready] [published]")
+order = [0, 6, 1, 2, 7, 3, 4, 5]
+for l in range(L):
+    for p in order:
+        r = tr[l * 8 + p]
+        extra = "  scores %.2f softmax %.2f pv %.2f" % (us(r[4]), us(r[5]), us(r[6])) if p >= 6 else ""
+        print("L%02d %-10s in %8.2f (%4d polls)  ready %8.2f  pub %8.2f%s" % (l, names[p], us(r[0]), r[1], us(r[2]) if r[2] else 0.0, us(r[3]), extra))
+r = tr[L * 8]
+print("final      in %8.2f (%4d polls)  ready %8.2f  done %8.2f" % (us(r[0]), r[1], us(r[2]), us(r[3])))

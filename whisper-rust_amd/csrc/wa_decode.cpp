@@ -179,7 +179,7 @@ static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & 
     a.kv_k = st.kv_self.k; a.kv_v = st.kv_self.v; a.kv_layer_stride = (unsigned long long) st.kv_self.size * hp.n_text_state;
     a.cross_k = st.d_cross_k; a.cross_v = st.d_cross_v;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * st.cross_tpad * 64; a.cross_tpad = st.cross_tpad; a.T = T;
-    a.granules = st.d_mega_gr; a.edge_stride = 2 * hp.n_text_state;
+    a.granules = st.d_mega_gr; a.edge_stride = 2 * hp.n_text_state; a.cross_gr = st.d_mega_cgr;
     a.logits = st.d_mega_out; a.status = st.d_mega_status; a.dbg = nullptr;
     a.token = token; a.pos = pos; a.n_kv = n_kv; a.kv_head = kv_head;
     a.kq_scale = pow(float(64), -0.25);       // whisper.cpp:2522
@@ -200,6 +200,10 @@ static int mega_step(whisper_context & ctx, whisper_state & st, int token, int p
         (void) hipMemcpyAsync(st.h_logits_pinned, st.d_mega_out, ((size_t) n_vocab + 1) * sizeof(float), hipMemcpyDeviceToHost, s);
         if (!WA_HIP_OK(hipStreamSynchronize(s))) { st.mega_enabled = false; return 0; }
         status = ((const unsigned *) st.h_logits_pinned)[n_vocab];
+    }
+    if (status == WA_MEGA_REDO) {      // an uncertifiable soft-max sum (~1e-9 per soft-max): this token goes through the launch sequence
+        (void) hipMemsetAsync(st.d_mega_status, 0, sizeof(unsigned), s);
+        return 0;
     }
     if (status != 0) {     // a hand-off timed out (workgroups not co-resident?): fall back for good
         WA_WARN("%s: one-launch decode step gave up at hand-off %u - using the launch sequence from now on\n", __func__, status);
@@ -379,10 +383,12 @@ extern "C" int whisper_amd_mega_debug(struct whisper_context * ctx, struct whisp
     wa_mega_args a;
     if (!mega_args(*ctx, *st, a, token, n_past, n_past + 1, n_past)) return -2;
     const auto & hp = ctx->model.hp;
-    const size_t n_dbg = (size_t) hp.n_text_layer * hp.n_text_head * 5120;
+    const size_t n_dbg = (size_t) hp.n_text_layer * hp.n_text_head * 5120 + 8192;
     if (getenv("WHISPER_AMD_MEGA_DBG")) { if (!d_dbg) (void) hipMalloc((void **) &d_dbg, n_dbg * 4); a.dbg = d_dbg; }
     std::lock_guard<std::mutex> lk(g_mega_mutex);
-    wa_launch_decode_mega(st->stream, a, std::min(ctx->model.n_cu, 256));
+    int n_wg = std::min(ctx->model.n_cu, 256);
+    if (const char * e = getenv("WHISPER_AMD_MEGA_WG")) n_wg = std::max(2 * hp.n_text_head + 1, std::min(n_wg, atoi(e)));
+    wa_launch_decode_mega(st->stream, a, n_wg);
     if (!WA_HIP_OK(hipStreamSynchronize(st->stream))) return -3;
     if (a.dbg) { std::vector<float> h(n_dbg); (void) hipMemcpy(h.data(), d_dbg, n_dbg * 4, hipMemcpyDeviceToHost); FILE * f = fopen("gpurun_out/mega_dbg.bin", "wb"); if (f) { fwrite(h.data(), 4, n_dbg, f); fclose(f); } }
     if (granules_out) (void) hipMemcpy(granules_out, st->d_mega_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * 2 * hp.n_text_state * 8, hipMemcpyDeviceToHost);

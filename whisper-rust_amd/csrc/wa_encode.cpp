@@ -84,9 +84,10 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
         const char * g = getenv("WHISPER_AMD_NO_MEGA");
         const int dt = hp.n_text_state, Ht = hp.n_text_head;
         st.mega_enabled = !(g && g[0] == '1') && ctx.model.d_mega_layers && ctx.model.n_loaded > 0 && dt == Ht * 64 && dt % 128 == 0 &&
-                          dt <= WA_MEGA_MAX_D && hp.n_audio_ctx <= 1500 && ctx.model.n_cu >= 2 * Ht + 16 && tpad <= WA_MEGA_MAX_T;
+                          dt <= WA_MEGA_MAX_D && hp.n_audio_ctx <= 1500 && ctx.model.n_cu >= 5 * Ht + 16 && tpad <= WA_MEGA_MAX_T;
         if (st.mega_enabled) {
             // logits of the step and, right behind them, the status word: one device-to-host copy per token
+            if (!dev_alloc(st.d_mega_cgr, (size_t) hp.n_text_layer * Ht * WA_MEGA_CGR)) return false;
             if (!dev_alloc(st.d_mega_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * 2 * dt) || !dev_alloc(st.d_mega_out, (size_t) hp.n_vocab + 64)) return false;
             st.d_mega_status = (unsigned *) (st.d_mega_out + hp.n_vocab);
         }
@@ -118,7 +119,7 @@ void wa_state_release(whisper_state & st) {
     dev_free(st.d_tok); dev_free(st.d_pos); dev_free(st.d_cell); dev_free(st.d_rows); dev_free(st.d_mask);
     dev_free(st.d_dx); dev_free(st.d_dxn); dev_free(st.d_dqkv); dev_free(st.d_dao); dev_free(st.d_dff); dev_free(st.d_dq);
     if (st.dec_graph) { (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr; }
-    dev_free(st.d_mega_gr); dev_free(st.d_mega_out); st.d_mega_status = nullptr;
+    dev_free(st.d_mega_gr); dev_free(st.d_mega_cgr); dev_free(st.d_mega_out); st.d_mega_status = nullptr;
     dev_free(st.d_dyn); dev_free(st.d_att_partial); dev_free(st.d_att_pleft); dev_free(st.d_im2col); dev_free(st.d_logits); dev_free(st.d_aheads_qk);
     if (st.h_stage_i32)     { (void) hipHostFree(st.h_stage_i32);     st.h_stage_i32 = nullptr; }
     if (st.h_stage_mask)    { (void) hipHostFree(st.h_stage_mask);    st.h_stage_mask = nullptr; }

@@ -230,6 +230,7 @@ struct whisper_state {
 
     // one-launch decode step (wa_mega.hip): hand-off granules [layer][8][2d], status word, launch sequence number
     unsigned long long * d_mega_gr = nullptr;
+    unsigned long long * d_mega_cgr = nullptr;   // [layer][head][2048]: exchange area of the cross-attention workgroups
     float * d_mega_out = nullptr;         // [n_vocab] logits + status word
     unsigned * d_mega_status = nullptr;   // = d_mega_out + n_vocab
     unsigned mega_seq = 0;

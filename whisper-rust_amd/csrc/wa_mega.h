@@ -26,6 +26,7 @@ struct wa_mega_args {
     const wa_f16 * cross_k, * cross_v; unsigned long long cross_layer_stride;   // cross K/V [layer][head][tpad][64]
     int cross_tpad, T;
     unsigned long long * granules; int edge_stride;                            // [layer][8][edge_stride] hand-off granules
+    unsigned long long * cross_gr;                                              // [layer][head][2048] exchange area of a head's four cross-attention workgroups
     float * logits;                                                             // [n_vocab]
     unsigned * status;                                                          // 0 = ok; else code of the hand-off that timed out
     float * dbg;                                                                // optional [layer][head][2][1536]: cross-attention scores, probabilities
@@ -34,6 +35,8 @@ struct wa_mega_args {
 };
 
 #define WA_MEGA_EDGES 8
+#define WA_MEGA_CGR 2048
+#define WA_MEGA_REDO 9000u      // status: a soft-max sum could not be certified order-independent - recompute this token with the launch sequence
 #define WA_MEGA_MAX_D 1280
 #define WA_MEGA_MAX_KV 512
 #define WA_MEGA_MAX_T 1536

@@ -55,9 +55,19 @@ __device__ __forceinline__ gu64 * mg_edge(mg_kargs A, int layer, int e) {
     return (gu64 *) A->granules + ((size_t) layer * WA_MEGA_EDGES + e) * A->edge_stride;
 }
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)), i.e. it
+// would make every wave wait here for the weights it has just started to prefetch - the opposite of what the prefetch is for.
+__device__ __forceinline__ void mg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// optional timeline (tools/mega_debug.py): 100 MHz wall-clock ticks of one workgroup per role, behind the cross-attention dumps
+__device__ __forceinline__ void mg_trace(mg_kargs A, bool who, int slot, unsigned v) {
+    if (A->dbg && who) ((GAS unsigned *) A->dbg)[(size_t) A->n_layer * A->n_head * 5120 + slot] = v;
+}
+__device__ __forceinline__ unsigned mg_now() { return (unsigned) wall_clock64(); }
+
 // One wave polls the granules idx(0..NPL-1) (idx < 0: none) until every tag equals this launch's sequence number.
 template <int NPL, typename F>
-__device__ __forceinline__ void mg_sweep(gu64 * g, F idx, mg_ctl & c, int lane, unsigned (&v)[NPL], unsigned code) {
+__device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int lane, unsigned (&v)[NPL], unsigned code) {
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
@@ -65,14 +75,14 @@ __device__ __forceinline__ void mg_sweep(gu64 * g, F idx, mg_ctl & c, int lane, 
             const int i = idx(k);
             if (i >= 0) { const u64 x = gr_load(g + i); v[k] = (unsigned) x; ok &= (unsigned) (x >> 32) == c.seq; }
         }
-        if (__all(ok) || c.dead) return;
+        if (__all(ok) || c.dead) return spins;
         if ((spins & 127u) == 127u) {
             const unsigned st = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (st != 0u) { c.dead = true; return; }
+            if (st != 0u) { c.dead = true; return spins; }
             if (spins >= MG_SPIN_LIMIT) {
                 if (lane == 0) __hip_atomic_store(c.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 c.dead = true;
-                return;
+                return spins;
             }
         }
         __builtin_amdgcn_s_sleep(1);
@@ -83,32 +93,39 @@ __device__ __forceinline__ void mg_sweep(gu64 * g, F idx, mg_ctl & c, int lane, 
 // wave 0 of a workgroup: obtain the F32 residual row (from granules, or from the embeddings for layer 0), keep it in
 // LDS (xf) and write LayerNorm(row) as F16 into xin.  ops.cpp:3225-3242 semantics, as k_layernorm_exact.
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge /* null: embeddings */, gcf lw, gcf lb, int lane, float * xf,
-                                             wa_f16 * xin, unsigned code) {
-    const int d = A->d;
-    float xv[MG_NPL], gw[MG_NPL], gb[MG_NPL];
+template <int NPL>
+__device__ __forceinline__ void mg_ln_params(float (&gw)[NPL], float (&gb)[NPL], const float * lw, const float * lb, int d, int lane) {
 #pragma unroll
-    for (int k = 0; k < MG_NPL; ++k) {            // gamma / beta do not depend on the hand-off: in flight while polling
+    for (int k = 0; k < NPL; ++k) {
         const int i = lane + 64 * k;
         const bool ok = i < d;
-        gw[k] = ok ? lw[i] : 0.0f; gb[k] = ok ? lb[i] : 0.0f;
+        gw[k] = ok ? ((gcf) lw)[i] : 0.0f; gb[k] = ok ? ((gcf) lb)[i] : 0.0f;
     }
+}
+// gw / gb: gamma and beta of THIS LayerNorm, loaded one phase ahead (a load issued here would sit, with its pointer fetch, in
+// front of the polling loads: measured 5 us per LayerNorm phase)
+template <int NPL>
+__device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge /* null: embeddings */, const float (&gw)[NPL], const float (&gb)[NPL],
+                                             int lane, float * xf, wa_f16 * xin, unsigned code, int tslot = -1) {
+    const int d = A->d;
+    float xv[NPL];
     if (edge) {
-        unsigned v[MG_NPL];
-        mg_sweep<MG_NPL>(edge, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
+        unsigned v[NPL];
+        const unsigned sp = mg_sweep<NPL>(edge, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
+        if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
 #pragma unroll
-        for (int k = 0; k < MG_NPL; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
+        for (int k = 0; k < NPL; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
     } else {                                      // k_dec_embed: token embedding + positional embedding
         const gch te = (gch) A->te + (size_t) A->token * d;
         const gcf pe = (gcf) A->pe + (size_t) A->pos * d;
 #pragma unroll
-        for (int k = 0; k < MG_NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? h2f(te[i]) + pe[i] : 0.0f; }
+        for (int k = 0; k < NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? h2f(te[i]) + pe[i] : 0.0f; }
     }
 #pragma unroll
-    for (int k = 0; k < MG_NPL; ++k) { const int i = lane + 64 * k; if (i < d) xf[i] = xv[k]; }
+    for (int k = 0; k < NPL; ++k) { const int i = lane + 64 * k; if (i < d) xf[i] = xv[k]; }
     double s = 0.0, a = 0.0;
 #pragma unroll
-    for (int k = 0; k < MG_NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
+    for (int k = 0; k < NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
     s = wave_sum_d(s); a = wave_sum_d(a);
     float mean;
     if (!wa_sum_certain(s, a, d, mean)) {
@@ -118,7 +135,7 @@ __device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge
     }
     double s2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < MG_NPL; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
+    for (int k = 0; k < NPL; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
     s2 = wave_sum_d(s2);
     float variance;
     if (!wa_sum_certain(s2, s2, d, variance)) {
@@ -128,7 +145,7 @@ __device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge
     }
     const float scale = 1.0f / sqrtf(variance + A->eps);
 #pragma unroll
-    for (int k = 0; k < MG_NPL; ++k) {
+    for (int k = 0; k < NPL; ++k) {
         const int i = lane + 64 * k;
         if (i < d) {
             float y = xv[k] - mean;
@@ -138,13 +155,16 @@ __device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge
             xin[i] = f2h(y);
         }
     }
+    if (tslot >= 0) mg_trace(A, lane == 0, tslot + 2, mg_now());
 }
 
 // wave(s): copy the packed-F16 granules [i0, i1) (two halfs each) into LDS once they are all valid
 template <int NPL>
-__device__ __forceinline__ void mg_gather_h2(mg_ctl & c, gu64 * edge, int i0, int i1, int lane, unsigned * dst32, unsigned code) {
+__device__ __forceinline__ void mg_gather_h2(mg_ctl & c, gu64 * edge, int i0, int i1, int lane, unsigned * dst32, unsigned code, mg_kargs A = nullptr,
+                                             int tslot = -1) {
     unsigned v[NPL];
-    mg_sweep<NPL>(edge, [&](int k) { const int i = i0 + lane + 64 * k; return i < i1 ? i : -1; }, c, lane, v, code);
+    const unsigned sp = mg_sweep<NPL>(edge, [&](int k) { const int i = i0 + lane + 64 * k; return i < i1 ? i : -1; }, c, lane, v, code);
+    if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
 #pragma unroll
     for (int k = 0; k < NPL; ++k) { const int i = i0 + lane + 64 * k; if (i < i1) dst32[i] = v[k]; }
 }
@@ -288,12 +308,14 @@ __device__ __forceinline__ void mg_prefetch_logits(mg_kargs A, unsigned (&pf)[96
     mg_pf8(pf, (gch) A->te + (size_t) (valid ? row : 0) * A->d + 4 * (lane & 7), valid, A->d >> 5, 0);
     have_pf = true;
 }
-__device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char * smem, unsigned (&pf)[96], bool have_pf, int lane, int wave) {
+template <int NPL>
+__device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char * smem, unsigned (&pf)[96], bool have_pf, const float (&gw)[NPL],
+                                         const float (&gb)[NPL], int lane, int wave) {
     float  * xf  = (float *) smem;
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);
     const int d = A->d, nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab;
-    if (wave == 0) mg_gather_ln(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, (gcf) A->lnf_w, (gcf) A->lnf_b, lane, xf, xin, 3000u);
-    __syncthreads();
+    if (wave == 0) mg_gather_ln<NPL>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, lane, xf, xin, 3000u, blockIdx.x == 0 ? (A->n_layer * 8) * 8 : -1);
+    mg_barrier();
     const int NG = (n_vocab + 7) >> 3;
     GAS float * logits = (GAS float *) A->logits;
     for (int j = 0;; ++j) {
@@ -305,6 +327,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
         const float r = mg_dot8(pf, wrow, valid, d >> 5, xin, lane & 7, j == 0 && have_pf);
         if (valid && (lane & 7) == 0) logits[row] = r;
     }
+    mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, (A->n_layer * 8) * 8 + 3, mg_now());
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -312,12 +335,13 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
 // wave 3 the two out-projections, wave 4 the cross query, wave 5 FC2; waves 6,7 help gather the 4d-wide FC2 input.
 // Every wave loads the weights of its NEXT task right after finishing the current one.
 // -------------------------------------------------------------------------------------------------
+template <int NPL>
 __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wg = blockIdx.x, nG = (int) gridDim.x - 2 * A->n_head;
+    const int wg = blockIdx.x, nG = (int) gridDim.x - 5 * A->n_head;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
     unsigned pf[96];
     bool have_pf = false;
@@ -328,11 +352,15 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     const int r_qkv = mg_rpw(3 * d, nG), r_d = mg_rpw(d, nG), r_ff = mg_rpw(d4, nG);
     const int row_qkv = wg * r_qkv, row_d = wg * r_d, row_ff = wg * r_ff;
     const int g_qkv = (r_qkv + 7) >> 3, g_ff = (r_ff + 7) >> 3, g_d8 = (r_d + 7) >> 3, g_d16 = (r_d + 3) >> 2;
-    const GAS wa_mega_layer * Ly = (const GAS wa_mega_layer *) A->layers;
+    // the layer table is read-only for the launch: constant address space = scalar loads (a vector load of a pointer costs a
+    // drained vmcnt in front of the barrier: measured 3 us per LayerNorm phase)
+    const __attribute__((address_space(4))) wa_mega_layer * Ly = (const __attribute__((address_space(4))) wa_mega_layer *) A->layers;
     const unsigned seq = c.seq;
     const int hf_seg = (((2 * d + 2) / 3 + 63) >> 6) << 6;      // FC2-input granules swept by each of the waves 0, 6, 7
     const int kv_head = A->kv_head;
 
+    float gw[NPL], gb[NPL];          // wave 0: gamma / beta of its next LayerNorm
+    if (wave == 0) mg_ln_params<NPL>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, lane);
     mg_task t; t.valid = false; t.row = 0; t.wrow = nullptr; t.bias = 0.f; t.scale = 1.f;
     if (wave == 1 || wave == 2) t = mg_task8(pf, Ly[0].qkv_w, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
     else if (wave == 3)         t = mg_task8(pf, Ly[0].out_w, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -341,10 +369,13 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     else if (wave >= 6)         mg_prefetch_logits(A, pf, have_pf, lane, wave);      // held until the final phase
 
     for (int l = 0; l < L; ++l) {
-        const GAS wa_mega_layer & Y = Ly[l];
+        const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         // ---------------- P1: LayerNorm + q|k|v ----------------
-        if (wave == 0) mg_gather_ln(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), (gcf) Y.ln1_w, (gcf) Y.ln1_b, lane, xf, xin, 100u + l);
-        __syncthreads();
+        if (wave == 0) {
+            mg_gather_ln<NPL>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, lane, xf, xin, 100u + l, wg == 0 ? (l * 8 + 0) * 8 : -1);
+            mg_ln_params<NPL>(gw, gb, Y.ln2_w, Y.ln2_b, d, lane);
+        }
+        mg_barrier();
         if (wave == 1 || wave == 2) {
             gu64 * eq = mg_edge(A, l, E_QKV);
             for (int grp = wave - 1; grp < g_qkv; grp += 2) {
@@ -359,11 +390,12 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
                     *(GAS unsigned *) cell = pk;
                 }
             }
+            mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 0) * 8 + 3, mg_now());
             t = mg_task8(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
         }
         // ---------------- P3: self-attention out-projection + residual ----------------
-        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO), 0, d >> 1, lane, (unsigned *) xin, 200u + l);
-        __syncthreads();
+        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO), 0, d >> 1, lane, (unsigned *) xin, 200u + l, A, wg == 0 ? (l * 8 + 1) * 8 : -1);
+        mg_barrier();
         if (wave == 3) {
             gu64 * ex = mg_edge(A, l, E_X1);
             for (int grp = 0; grp < g_d8; ++grp) {
@@ -372,11 +404,15 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
+            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 1) * 8 + 3, mg_now());
             t = mg_task8(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
-        if (wave == 0) mg_gather_ln(A, c, mg_edge(A, l, E_X1), (gcf) Y.ln2_w, (gcf) Y.ln2_b, lane, xf, xin, 300u + l);
-        __syncthreads();
+        if (wave == 0) {
+            mg_gather_ln<NPL>(A, c, mg_edge(A, l, E_X1), gw, gb, lane, xf, xin, 300u + l, wg == 0 ? (l * 8 + 2) * 8 : -1);
+            mg_ln_params<NPL>(gw, gb, Y.ln3_w, Y.ln3_b, d, lane);
+        }
+        mg_barrier();
         if (wave == 4) {
             gu64 * eq = mg_edge(A, l, E_QC);
             for (int grp = 0; grp < g_d8; ++grp) {
@@ -385,11 +421,12 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
                 v = v + t.bias;
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
+            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P6: cross-attention out-projection + residual ----------------
-        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO2), 0, d >> 1, lane, (unsigned *) xin, 400u + l);
-        __syncthreads();
+        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO2), 0, d >> 1, lane, (unsigned *) xin, 400u + l, A, wg == 0 ? (l * 8 + 3) * 8 : -1);
+        mg_barrier();
         if (wave == 3) {
             gu64 * ex = mg_edge(A, l, E_X2);
             for (int grp = 0; grp < g_d8; ++grp) {
@@ -398,11 +435,16 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
+            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
-        if (wave == 0) mg_gather_ln(A, c, mg_edge(A, l, E_X2), (gcf) Y.ln3_w, (gcf) Y.ln3_b, lane, xf, xin, 500u + l);
-        __syncthreads();
+        if (wave == 0) {
+            mg_gather_ln<NPL>(A, c, mg_edge(A, l, E_X2), gw, gb, lane, xf, xin, 500u + l, wg == 0 ? (l * 8 + 4) * 8 : -1);
+            if (l + 1 < L) mg_ln_params<NPL>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, lane);
+            else           mg_ln_params<NPL>(gw, gb, A->lnf_w, A->lnf_b, d, lane);
+        }
+        mg_barrier();
         if (wave == 1 || wave == 2) {
             gu64 * eh = mg_edge(A, l, E_HF);
             const gch gelu = (gch) A->gelu;
@@ -414,15 +456,16 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
                 if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu[t.valid ? f2h(v) : 0]);
                 mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
             }
+            mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
         }
         // ---------------- P8: FC2 + residual ----------------
         if (wave == 0 || wave >= 6) {
             const int gi = wave == 0 ? 0 : wave - 5;
             const int i0 = gi * hf_seg, i1 = min(2 * d, i0 + hf_seg);
-            mg_gather_h2<(((2 * WA_MEGA_MAX_D + 2) / 3 + 63) / 64)>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l);
+            mg_gather_h2<(((2 * WA_MEGA_MAX_D + 2) / 3 + 63) / 64)>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
-        __syncthreads();
+        mg_barrier();
         if (wave == 5) {
             gu64 * ex = mg_edge(A, l, E_X3);
             for (int grp = 0; grp < g_d16; ++grp) {
@@ -431,11 +474,12 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
                 v = v + t.bias;
                 if (t.valid && (lane & 15) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
+            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 5) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task16(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
         }
     }
     if (wave >= 1 && wave <= 5) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    mg_final(A, c, smem, pf, have_pf, lane, wave);
+    mg_final<NPL>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -460,19 +504,19 @@ __device__ __forceinline__ void mg_softmax(const mg_att_smem & M, int n_kv, floa
     float * sc = M.sc;
     lmax = wave_max(lmax);
     if (lane == 0) M.red[wave] = lmax;
-    __syncthreads();
+    mg_barrier();
     float mx = M.red[0];
 #pragma unroll
     for (int w = 1; w < MG_NW; ++w) mx = fmaxf(mx, M.red[w]);
     const int n8 = n_kv & ~7;
     if (dbg) for (int cc = tid; cc < n_kv; cc += MG_THREADS) dbg[cc] = sc[cc];
     for (int cc = tid; cc < n_kv; cc += MG_THREADS) sc[cc] = cc < n8 ? wa_expf(sc[cc] - mx) : wa_expf_libm(sc[cc] - mx);
-    __syncthreads();
+    mg_barrier();
     for (int g = tid; g < (n8 >> 3); g += MG_THREADS) {
         const float * v = &sc[g * 8];
         M.gs[g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
     }
-    __syncthreads();
+    mg_barrier();
     {
         double ps = 0.0;
         const int ng = n8 >> 3;
@@ -480,7 +524,7 @@ __device__ __forceinline__ void mg_softmax(const mg_att_smem & M, int n_kv, floa
         for (int cc = n8 + tid; cc < n_kv; cc += MG_THREADS) ps += (double) sc[cc];
         ps = wave_sum_d(ps);
         if (lane == 0) M.redd[wave] = ps;
-        __syncthreads();
+        mg_barrier();
         if (tid == 0) {
             double sum = 0.0;
 #pragma unroll
@@ -494,11 +538,11 @@ __device__ __forceinline__ void mg_softmax(const mg_att_smem & M, int n_kv, floa
                 *M.s_inv = (float) (1.0 / sum);
             } else *M.s_inv = ilo;
         }
-        __syncthreads();
+        mg_barrier();
     }
     const float inv = *M.s_inv;
     for (int cc = tid; cc < n_kv; cc += MG_THREADS) { M.p16[cc] = f2h(sc[cc] * inv); if (dbg) dbg[1536 + cc] = sc[cc] * inv; }
-    __syncthreads();
+    mg_barrier();
 }
 
 // one key's score from its two 16-byte pieces (lane a of the key's 4-lane group): k_attn_exact's arithmetic
@@ -547,7 +591,7 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
     const mg_kargs A = mg_uniform(A_);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = (int) blockIdx.x - ((int) gridDim.x - 2 * A->n_head);
+    const int h = (int) blockIdx.x - ((int) gridDim.x - 5 * A->n_head);
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
 
     wa_f16 * Ks = (wa_f16 *) smem;                                  // [512][64]
@@ -575,16 +619,17 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
                 if (idx < n16) { *(u32x4 *) (Ks + (size_t) idx * 8) = tk[j]; *(u32x4 *) (Vs + (size_t) idx * 8) = tv[j]; }
             }
         }
-        __syncthreads();
+        mg_barrier();
         if (wave == 0) {    // q | k | v of this head: three runs of 32 packed granules
             unsigned v[2];
-            mg_sweep<2>(mg_edge(A, l, E_QKV), [&](int k) {
+            const unsigned sp = mg_sweep<2>(mg_edge(A, l, E_QKV), [&](int k) {
                 if (k == 0) return (lane < 32 ? 0 : (d >> 1)) + h * 32 + (lane & 31);
                 return lane < 32 ? d + h * 32 + lane : -1; }, c, lane, v, 1000u + l);
+            mg_trace(A, h == 0 && lane == 0, (l * 8 + 6) * 8 + 0, mg_now()); mg_trace(A, h == 0 && lane == 0, (l * 8 + 6) * 8 + 1, sp);
             if (lane < 32) { ((unsigned *) M.qs)[lane] = v[0]; ((unsigned *) (Vs + (size_t) kv_head * 64))[lane] = v[1]; }
             else ((unsigned *) (Ks + (size_t) kv_head * 64))[lane - 32] = v[0];
         }
-        __syncthreads();
+        mg_barrier();
         // ---- scores: 4 lanes per key ----
         float lmax = -INFINITY;
         {
@@ -598,7 +643,9 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
                 if (cc < n_kv) { if (a == 0) M.sc[cc] = r; lmax = fmaxf(lmax, r); }
             }
         }
+        mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 4, mg_now());
         mg_softmax(M, n_kv, lmax, tid, lane, wave);
+        mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 5, mg_now());
         // ---- P V: chains r = cell mod 32 (4 per wave), lane = d_head index ----
         const int np = n_kv & ~31, nsteps = np >> 5;
         {
@@ -612,147 +659,209 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) M.part[(r0 + i) * 64 + lane] = acc[i];
         }
-        __syncthreads();
+        mg_barrier();
         mg_attn_finish(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid);
-        __syncthreads();
+        mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 3, mg_now());
+        mg_barrier();
     }
     unsigned pf[96];
     bool have_pf = false;
+    float gw[MG_NPL], gb[MG_NPL];
     if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    mg_final(A, c, smem, pf, have_pf, lane, wave);
+    else mg_ln_params<MG_NPL>(gw, gb, A->lnf_w, A->lnf_b, A->d, lane);
+    mg_final<MG_NPL>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 // -------------------------------------------------------------------------------------------------
-// role: cross-attention of head h over the encoder K/V (whisper.cpp:2683-2758), every layer.  One workgroup holds the
-// whole head on chip: the first 1024 keys in LDS, the rest of K as 2 x 16 bytes per (key, lane-of-4) in registers, V as
-// the 2 x 47 packed pairs of each half-wave's two partial-sum chains in registers; everything is loaded right after the
-// previous layer's result has been published, i.e. a whole layer ahead of the query that needs it.
+// role: cross-attention over the encoder K/V (whisper.cpp:2683-2758), every layer; FOUR workgroups per head.
+// The score and soft-max arithmetic of one head is VALU-bound on one CU (3 + 5 us measured), so the head's keys are
+// split so that every piece of the reference's summation structure stays inside one workgroup: workgroup w owns the
+// cells c with (c mod 32) in [8w, 8w + 8), i.e. the partial-sum chains 8w..8w+7 of the P V product AND the soft-max
+// groups g = c / 8 with g mod 4 == w (whole groups of 8 consecutive cells).  Per workgroup: 376 keys (K: 24 VGPRs
+// per lane, V: one 2-byte element per step and lane), both loaded a whole layer ahead.  The four exchange
+//   (1) their local maxima (one granule each),  (2) their F64 partial sums of the group sums (two granules each),
+//   (3) their 8 x 64 chain sums + the probabilities of their leftover cells, gathered by workgroup 0, which runs the
+//       final tree, the F64 leftovers and publishes the head's output.
+// The F64 sum is order-independent when certified (k_attn_exact); an uncertified sum (~1e-9 per soft-max) raises
+// status WA_MEGA_REDO and the host recomputes the token with the launch sequence.
 // -------------------------------------------------------------------------------------------------
-#define MG_CK_LDS 1024                                  // keys of the head kept in LDS
-#define MG_CPASS_R ((WA_MEGA_MAX_T - MG_CK_LDS) / 128)  // register passes of 128 keys behind them
-#define MG_CSTEPS 47
+#define MG_CSTEPS 48                                    // steps of a chain incl. the leftover step: T <= 1535
+#define MG_CGR 2048                                     // granules per (layer, head) of the cross exchange area
+#define MG_CGR_MAX 0
+#define MG_CGR_SUM 8
+#define MG_CGR_PART 64                                  // + (w - 1) * 576: 512 chain sums + 8 leftover probabilities
 
 __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = (int) blockIdx.x - ((int) gridDim.x - A->n_head);
+    const int H = A->n_head;
+    const int ci = (int) blockIdx.x - ((int) gridDim.x - 4 * H);
+    const int h = ci >> 2, w = ci & 3;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+    const unsigned seq = c.seq;
 
-    wa_f16 * Kl = (wa_f16 *) smem;                                   // [1024][64]
-    wa_f16 * vleft = Kl + (size_t) MG_CK_LDS * 64;                   // [32][64]
-    const mg_att_smem M = mg_att_carve(smem + (size_t) MG_CK_LDS * 64 * 2 + 32 * 64 * 2, WA_MEGA_MAX_T);
+    // LDS: part [32][64] f32 | vleft [32][64] f16 | sc [384] f32 | p16 [384] f16 | pleft [32] f16 | qs [64] f16 | red [8] | redd [8] | bc [4]
+    float  * part  = (float *) smem;
+    wa_f16 * vleft = (wa_f16 *) (smem + 8192);
+    float  * sc    = (float *) (smem + 8192 + 4096);
+    wa_f16 * p16   = (wa_f16 *) (smem + 8192 + 4096 + 1536);
+    wa_f16 * pleft = (wa_f16 *) (smem + 8192 + 4096 + 1536 + 768);
+    wa_f16 * qs    = (wa_f16 *) (smem + 8192 + 4096 + 1536 + 768 + 64);
+    double * redd  = (double *) (smem + 8192 + 4096 + 1536 + 768 + 64 + 128);
+    float  * red   = (float *) (smem + 8192 + 4096 + 1536 + 768 + 64 + 128 + 64);
+    float  * bc    = red + 8;
+
     const int T = A->T, tpad = A->cross_tpad, L = A->n_layer;
     const float kq_scale = A->kq_scale;
-    const int a = tid & 3, kslot = tid >> 2;
-    const int np = T & ~31, nsteps = np >> 5, nl = T - np;
-    const int hw = lane >> 5, l2 = lane & 31;
-    const int n_lds = T < MG_CK_LDS ? T : MG_CK_LDS;
+    const int a = tid & 3, ks = tid >> 2;
+    const int np = T & ~31, nsteps = np >> 5, nl = T - np, n8 = T & ~7, ng = n8 >> 3;
     for (int l = 0; l < L; ++l) {
+        gu64 * X = (gu64 *) A->cross_gr + ((size_t) l * H + h) * MG_CGR;
         const gch kp = (gch) A->cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
         const gch vp = (gch) A->cross_v + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
-        u32x4 ka[MG_CPASS_R], kb[MG_CPASS_R];
-        unsigned vv[2][MG_CSTEPS];
+        // ---- prefetch (a whole layer ahead of the query): own keys, own chain elements, leftover V rows ----
+        u32x4 ka[3], kb[3];
+        unsigned short vv[MG_CSTEPS];
 #pragma unroll
-        for (int b = 0; b < MG_CPASS_R; ++b) {
-            const int cc = MG_CK_LDS + b * 128 + kslot;
-            if (cc < tpad && MG_CK_LDS + b * 128 < T) {
-                ka[b] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 8 * a); kb[b] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 32 + 8 * a);
-            }
+        for (int p = 0; p < 3; ++p) {
+            const int o = p * 128 + ks, cc = 32 * (o >> 3) + 8 * w + (o & 7);
+            if (cc < T) { ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 8 * a); kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 32 + 8 * a); }
         }
 #pragma unroll
-        for (int s = 0; s < MG_CSTEPS; ++s) {
-            if (s < nsteps) {
-#pragma unroll
-                for (int ci = 0; ci < 2; ++ci) vv[ci][s] = *(const GAS unsigned *) (vp + (size_t) (s * 32 + wave * 4 + hw * 2 + ci) * 64 + 2 * l2);
-            }
-        }
-        {   // keys [0, n_lds) -> LDS, 16 bytes per thread per pass
-            const int n16 = n_lds * 8;
-#pragma unroll
-            for (int j0 = 0; j0 < 16; j0 += 8) {
-                u32x4 tk[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const int idx = tid + MG_THREADS * (j0 + j); if (idx < n16) tk[j] = *(const GAS u32x4 *) (kp + (size_t) idx * 8); }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const int idx = tid + MG_THREADS * (j0 + j); if (idx < n16) *(u32x4 *) (Kl + (size_t) idx * 8) = tk[j]; }
-            }
-        }
-        if (tid < 256) {       // the T % 32 leftover rows of V
+        for (int s = 0; s < MG_CSTEPS; ++s) if (s < nsteps) vv[s] = *(const GAS unsigned short *) (vp + (size_t) (32 * s + 8 * w + wave) * 64 + lane);
+        if (w == 0 && tid < 256) {
             const int row = tid >> 3;
             if (row < nl) *(u32x4 *) (vleft + (size_t) tid * 8) = *(const GAS u32x4 *) (vp + (size_t) (np + row) * 64 + (tid & 7) * 8);
         }
         if (wave == 0) {
             unsigned v[1];
-            mg_sweep<1>(mg_edge(A, l, E_QC), [&](int) { return lane < 32 ? h * 32 + lane : -1; }, c, lane, v, 2000u + l);
-            if (lane < 32) ((unsigned *) M.qs)[lane] = v[0];
+            mg_trace(A, ci == 0 && lane == 0, (l * 8 + 7) * 8 + 2, mg_now());
+            const unsigned sp = mg_sweep<1>(mg_edge(A, l, E_QC), [&](int) { return lane < 32 ? h * 32 + lane : -1; }, c, lane, v, 2000u + l);
+            mg_trace(A, ci == 0 && lane == 0, (l * 8 + 7) * 8 + 0, mg_now()); mg_trace(A, ci == 0 && lane == 0, (l * 8 + 7) * 8 + 1, sp);
+            if (lane < 32) ((unsigned *) qs)[lane] = v[0];
         }
-        __syncthreads();
+        mg_barrier();
+        // ---- scores of the own cells (local index o = 8 s + r  <->  cell 32 s + 8 w + r) ----
         float lmax = -INFINITY;
         {
             float qa[8], qb[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { qa[i] = h2f(M.qs[8 * a + i]); qb[i] = h2f(M.qs[32 + 8 * a + i]); }
-            for (int c0 = 0; c0 < n_lds; c0 += 128) {
-                const int cc = c0 + kslot, cl = cc < n_lds ? cc : n_lds - 1;
-                const u32x4 k0 = *(const u32x4 *) (Kl + (size_t) cl * 64 + 8 * a), k1 = *(const u32x4 *) (Kl + (size_t) cl * 64 + 32 + 8 * a);
-                const float r = mg_score(k0, k1, qa, qb, kq_scale);
-                if (cc < n_lds) { if (a == 0) M.sc[cc] = r; lmax = fmaxf(lmax, r); }
-            }
+            for (int i = 0; i < 8; ++i) { qa[i] = h2f(qs[8 * a + i]); qb[i] = h2f(qs[32 + 8 * a + i]); }
 #pragma unroll
-            for (int b = 0; b < MG_CPASS_R; ++b) {
-                if (MG_CK_LDS + b * 128 < T) {
-                    const int cc = MG_CK_LDS + b * 128 + kslot;
-                    const float r = mg_score(ka[b], kb[b], qa, qb, kq_scale);
-                    if (cc < T) { if (a == 0) M.sc[cc] = r; lmax = fmaxf(lmax, r); }
-                }
+            for (int p = 0; p < 3; ++p) {
+                const int o = p * 128 + ks, cc = 32 * (o >> 3) + 8 * w + (o & 7);
+                const float r = mg_score(ka[p], kb[p], qa, qb, kq_scale);
+                if (cc < T) { if (a == 0) sc[o] = r; lmax = fmaxf(lmax, r); }
             }
         }
-        mg_softmax(M, T, lmax, tid, lane, wave, A->dbg ? (GAS float *) A->dbg + ((size_t) l * A->n_head + h) * 5120 : nullptr);
+        lmax = wave_max(lmax);
+        if (lane == 0) red[wave] = lmax;
+        mg_barrier();
+        if (wave == 0) {        // (1) maxima of the four workgroups
+            float m = red[0];
+#pragma unroll
+            for (int k = 1; k < MG_NW; ++k) m = fmaxf(m, red[k]);
+            if (lane == 0) gr_store(X + MG_CGR_MAX + w, seq, __float_as_uint(m));
+            unsigned v[1];
+            mg_sweep<1>(X + MG_CGR_MAX, [&](int) { return lane < 4 ? lane : -1; }, c, lane, v, 2100u + l);
+            float g = lane < 4 ? __uint_as_float(v[0]) : -INFINITY;
+            g = fmaxf(g, dpp_f32<0x4e>(g)); g = fmaxf(g, dpp_f32<0xb1>(g));      // max over lanes 0..3
+            if (lane == 0) bc[0] = g;
+        }
+        mg_barrier();
+        mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 4, mg_now());
+        const float mx = bc[0];
+        // ---- exp, group sums, F64 partial sum: thread = one own group of 8 cells (ops.cpp:4792-4818, vec.cpp:257-308) ----
+        double ps = 0.0;
+        if (tid < MG_CSTEPS) {
+            const int g = 4 * tid + w;                      // global group index of local step tid
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int cc = 8 * g + r;
+                e[r] = cc < n8 ? wa_expf(sc[8 * tid + r] - mx) : (cc < T ? wa_expf_libm(sc[8 * tid + r] - mx) : 0.0f);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sc[8 * tid + r] = e[r];
+            if (g < ng) ps = (double) (((e[0] + e[4]) + (e[2] + e[6])) + ((e[1] + e[5]) + (e[3] + e[7])));
+            else { for (int r = 0; r < 8; ++r) if (8 * g + r < T) ps += (double) e[r]; }     // the n % 8 tail cells, index order
+        }
+        if (wave == 0) {        // (2) partial sums -> total, certified
+            ps = wave_sum_d(ps);
+            const u64 pb = (u64) __double_as_longlong(ps);
+            if (lane == 0) { gr_store(X + MG_CGR_SUM + 2 * w, seq, (unsigned) pb); gr_store(X + MG_CGR_SUM + 2 * w + 1, seq, (unsigned) (pb >> 32)); }
+            unsigned v[1];
+            mg_sweep<1>(X + MG_CGR_SUM, [&](int) { return lane < 8 ? lane : -1; }, c, lane, v, 2200u + l);
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned lo = __builtin_amdgcn_readlane(v[0], 2 * k), hi = __builtin_amdgcn_readlane(v[0], 2 * k + 1);
+                tot += __longlong_as_double((long long) (((u64) hi << 32) | lo));
+            }
+            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
+            const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
+            if (ilo != ihi && lane == 0 && !c.dead) __hip_atomic_store(c.status, (unsigned) WA_MEGA_REDO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) bc[1] = ilo;
+        }
+        mg_barrier();
+        mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 5, mg_now());
+        const float inv = bc[1];
+        if (tid < 8 * MG_CSTEPS) {
+            const int cc = 32 * (tid >> 3) + 8 * w + (tid & 7);
+            if (cc < T) {
+                const wa_f16 ph = f2h(sc[tid] * inv);
+                p16[tid] = ph;
+                if (cc >= np) { if (w == 0) pleft[cc - np] = ph; else gr_store(X + MG_CGR_PART + (w - 1) * 576 + 512 + (tid & 7), seq, (unsigned) ph); }
+            }
+        }
+        mg_barrier();
+        // ---- P V: wave = own chain (cells 32 s + 8 w + wave), lane = d_head index ----
         {
-            float acc[2][2] = { { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+            float acc = 0.0f;
 #pragma unroll
-            for (int s = 0; s < MG_CSTEPS; ++s) {
-                if (s < nsteps) {
-#pragma unroll
-                    for (int ci = 0; ci < 2; ++ci) {
-                        const float p = h2f(M.p16[s * 32 + wave * 4 + hw * 2 + ci]);
-                        const half2v v2 = __builtin_bit_cast(half2v, vv[ci][s]);
-                        acc[ci][0] = fmaf((float) v2[0], p, acc[ci][0]);
-                        acc[ci][1] = fmaf((float) v2[1], p, acc[ci][1]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int ci = 0; ci < 2; ++ci) {
-                M.part[(wave * 4 + hw * 2 + ci) * 64 + 2 * l2]     = acc[ci][0];
-                M.part[(wave * 4 + hw * 2 + ci) * 64 + 2 * l2 + 1] = acc[ci][1];
-            }
+            for (int s = 0; s < MG_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(vv[s]), h2f(p16[8 * s + wave]), acc);
+            if (w == 0) part[wave * 64 + lane] = acc;
+            else gr_store(X + MG_CGR_PART + (w - 1) * 576 + wave * 64 + lane, seq, __float_as_uint(acc));
         }
-        __syncthreads();
-        if (A->dbg) for (int i = tid; i < 2048; i += MG_THREADS) ((GAS float *) A->dbg)[((size_t) l * A->n_head + h) * 5120 + 3072 + i] = M.part[i];
-        mg_attn_finish(M.part, vleft, M.p16, np, nl, mg_edge(A, l, E_AO2), h, c.seq, tid);
-        __syncthreads();
+        mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 6, mg_now());
+        if (w == 0) {           // (3) gather the other three workgroups' chain sums and leftover probabilities, finish the head
+            if (wave >= 1 && wave <= 6) {
+                const int ww = (wave - 1) >> 1, half = (wave - 1) & 1;       // source workgroup ww + 1, rows [4 half, 4 half + 4) of its 8 chains
+                gu64 * src = X + MG_CGR_PART + ww * 576;
+                unsigned v[5];
+                mg_sweep<5>(src, [&](int k) { return k < 4 ? half * 256 + 64 * k + lane : (half == 0 && lane < 8 && 8 * (ww + 1) + lane < nl ? 512 + lane : -1); }, c, lane, v, 2300u + l);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part[(8 * (ww + 1) + 4 * half + k) * 64 + lane] = __uint_as_float(v[k]);
+                if (half == 0 && lane < 8) { const int cc = 8 * (ww + 1) + lane; if (cc < nl) pleft[cc] = (wa_f16) v[4]; }
+            }
+            mg_barrier();
+            mg_attn_finish(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid);
+            mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 3, mg_now());
+        }
+        mg_barrier();
     }
     unsigned pf[96];
     bool have_pf = false;
+    float gw[MG_NPL], gb[MG_NPL];
     if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    mg_final(A, c, smem, pf, have_pf, lane, wave);
+    else mg_ln_params<MG_NPL>(gw, gb, A->lnf_w, A->lnf_b, A->d, lane);
+    mg_final<MG_NPL>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A) {
-    const int nG = (int) gridDim.x - 2 * A.n_head;
+    const int nG = (int) gridDim.x - 5 * A.n_head;       // H self-attention + 4 H cross-attention workgroups
     const int wg = blockIdx.x;
     const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();     // = &A (the struct is the only argument)
-    if (wg < nG)                 mg_role_gemv(Ap);
+    if (wg < nG) { if (A.d <= 768) mg_role_gemv<12>(Ap); else mg_role_gemv<MG_NPL>(Ap); }
     else if (wg < nG + A.n_head) mg_role_self(Ap);
     else                         mg_role_cross(Ap);
 }
 
 size_t wa_mega_lds_bytes() {
     const size_t s_self  = (size_t) WA_MEGA_MAX_KV * 64 * 2 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_KV);
-    const size_t s_cross = (size_t) MG_CK_LDS * 64 * 2 + 32 * 64 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_T);
+    const size_t s_cross = 8192 + 4096 + 1536 + 768 + 64 + 128 + 64 + 32 + 16;
     const size_t s_gemv  = (size_t) WA_MEGA_MAX_D * 4 + (size_t) 4 * WA_MEGA_MAX_D * 2;
     size_t m = s_self > s_cross ? s_self : s_cross;
     m = m > s_gemv ? m : s_gemv;
