@@ -203,7 +203,11 @@ def main():
         dbytes = decode_bytes(shape, n_past)
         if rc == 0 and ms.value > 0:
             gbs = dbytes / (ms.value * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "decode step = hipGraph of 122 launches (k_gemv_exact weight streaming + k_attn_exact), 1 token, n_past=64",
+            lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
+            kname = ("k_decode_mega: the whole single-token decoder pass as ONE persistent launch (256 workgroups, granule hand-offs), n_past=64"
+                     if lib.whisper_amd_mega_enabled(st.ptr) else
+                     "decode step = hipGraph of 122 launches (k_gemv_exact weight streaming + k_attn_exact), 1 token, n_past=64")
+            out["roofline"] = {"bound": "hbm", "kernel": kname,
                                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                "traffic": None, "bytes_per_step": dbytes, "ms_per_step_device": round(ms.value, 4),
                                "ms_per_token_wall_in_full": round(dec_ms_wall, 4)}

@@ -270,3 +270,28 @@ def test_small_shape_properties(wrs, amd_lib):
     assert digest(st.get_logits_last(len(toks) - 8)) == digest(batch)
     assert np.isfinite(batch).all()
     st.free(); ctx.free()
+
+
+@pytest.mark.parametrize("name,n_tok", [("s128", 40), ("tiny", 24), ("small", 48)])
+def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok, monkeypatch):
+    """The single-token decoder pass as ONE persistent launch (wa_mega.hip) against the launch sequence (which the tests
+    above pin to the reference): bit-identical logits token by token, over enough tokens that n_kv crosses the n % 8 and
+    n % 32 boundaries of the soft-max / P V leftovers; and the one-launch path must actually be the one that ran."""
+    amd_lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
+    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path(name), wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "1"); ref = ctx.create_state()
+    monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "0"); meg = ctx.create_state()
+    assert amd_lib.whisper_amd_mega_enabled(ref.ptr) == 0 and amd_lib.whisper_amd_mega_enabled(meg.ptr) == 1
+    pcm = wsynth.synth_audio(480000, 1)
+    sot = ctx.token_sot()
+    prompt = [sot, sot + 1, sot + 102]
+    for st in (ref, meg):
+        st.pcm_to_mel(pcm); st.encode(0); st.decode(prompt, 0)
+    tok = int(np.argmax(ref.get_logits_last(len(prompt))[:50000]))
+    for i in range(n_tok):
+        ref.decode([tok], len(prompt) + i); meg.decode([tok], len(prompt) + i)
+        a = ref.get_logits_last(1); b = meg.get_logits_last(1)
+        assert digest(a) == digest(b), "token %d (n_kv %d): max|d| = %g" % (i, len(prompt) + i + 1, float(np.abs(a - b).max()))
+        tok = int(np.argmax(a[:50000]))
+    assert amd_lib.whisper_amd_mega_enabled(meg.ptr) == 1, "the one-launch step gave up (hand-off time-out) and fell back"
+    ref.free(); meg.free(); ctx.free()

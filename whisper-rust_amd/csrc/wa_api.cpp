@@ -692,9 +692,14 @@ int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state **
     std::vector<int> rc(n_chunks, 0);
     std::vector<std::thread> th;
     th.reserve(n_chunks);
+    // The one-launch decode step fills the chip by itself and is exclusive per device (wa_decode.cpp), so concurrent chunks
+    // would queue behind each other token by token: with several chunks in flight the launch sequence overlaps better.
+    std::vector<char> mega(n_chunks, 0);
+    if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) { mega[i] = states[i]->mega_enabled; states[i]->mega_enabled = false; }
     for (int i = 0; i < n_chunks; ++i)
         th.emplace_back([&, i]() { rc[i] = whisper_full_with_state(ctx, states[i], params, samples[i], n_samples[i]); });
     for (auto & t : th) t.join();
+    if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) states[i]->mega_enabled = mega[i];
     for (int r : rc) if (r != 0) return r;
     return 0;
 }
