@@ -232,6 +232,10 @@ def main():
                           "frac": round(eflops / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if enc_ms > 0 else None,
                           "mel_ms": round(1e-3 * t_mel, 3)}
         out["host_sampling_ms_per_token"] = round(1e-3 * t_sample / max(1, n_decode), 4)
+        ov = (C.c_int * 2)()
+        lib.whisper_amd_overlap_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.whisper_amd_overlap_stats(st.ptr, ov)
+        out["host_overlap"] = {"predictions_confirmed": int(ov[0]), "predictions_wrong": int(ov[1])}
 
         # ---- CPU baseline: the reference engine on this box's host cores (rank 0, N == 1 only)
         ref_path = os.path.join(ROOT, "oracle", "_ref", "libwhisper_ref.so")

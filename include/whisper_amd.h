@@ -469,6 +469,11 @@ WHISPER_API int whisper_amd_decode_step_probe(struct whisper_context * ctx, stru
  * captured launch sequence (WHISPER_AMD_NO_MEGA=1, unsupported shape, or after a hand-off time-out). */
 WHISPER_API int whisper_amd_mega_enabled(struct whisper_state * state);
 
+/* Host-overlapped greedy decoding (the device decodes its own prediction of the next token while the host applies the
+ * reference's sampling rules to the previous logits): out = { predictions confirmed, predictions wrong (step redone) }
+ * since the last whisper_amd_reset_timings. */
+WHISPER_API void whisper_amd_overlap_stats(struct whisper_state * state, int out[2]);
+
 /* Debugging aid (tools/mega_check.py): runs the one-launch step for (token, position n_past) on KV cell n_past and copies
  * out the hand-off granules [n_text_layer][8][2 * n_text_state] (tag << 32 | value bits) and the logits [n_vocab].
  * Returns the step's status word (0 = ok), < 0 when the one-launch step is not available. */

@@ -513,7 +513,9 @@ void whisper_print_timings(struct whisper_context * ctx) {
 void whisper_amd_reset_timings(struct whisper_state * s) {
     s->t_mel_us = s->t_sample_us = s->t_encode_us = s->t_decode_us = s->t_batchd_us = s->t_prompt_us = 0;
     s->n_sample = s->n_encode = s->n_decode = s->n_batchd = s->n_prompt = 0;
+    s->n_spec_ok = s->n_spec_miss = 0;
 }
+void whisper_amd_overlap_stats(struct whisper_state * s, int out[2]) { out[0] = s->n_spec_ok; out[1] = s->n_spec_miss; }
 void whisper_reset_timings(struct whisper_context * ctx) {
     ctx->t_start_us = wa_time_us();
     if (ctx->state) whisper_amd_reset_timings(ctx->state);

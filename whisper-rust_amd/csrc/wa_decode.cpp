@@ -182,6 +182,10 @@ static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & 
     a.granules = st.d_mega_gr; a.edge_stride = 2 * hp.n_text_state; a.cross_gr = st.d_mega_cgr;
     a.logits = st.d_mega_out; a.status = st.d_mega_status; a.dbg = nullptr;
     a.token = token; a.pos = pos; a.n_kv = n_kv; a.kv_head = kv_head;
+    a.spec = 0; a.rec_in = st.d_mega_rec[1]; a.rec_out = st.d_mega_rec[0]; a.n_rec = std::min(m.n_cu, 256);
+    a.ps_in = st.d_mega_ps[1]; a.ps_out = st.d_mega_ps[0]; a.smask = st.d_mega_smask;
+    a.token_beg = ctx.vocab.token_beg; a.token_eot = ctx.vocab.token_eot;
+    a.s_last = token; a.s_penult = -1; a.s_seek_delta = 0; a.s_has_ts = 0;
     a.kq_scale = pow(float(64), -0.25);       // whisper.cpp:2522
     st.mega_seq += 1; if (st.mega_seq == 0) st.mega_seq = 1;
     a.seq = st.mega_seq;
@@ -212,6 +216,82 @@ static int mega_step(whisper_context & ctx, whisper_state & st, int token, int p
         return 0;
     }
     return 1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// host overlap for greedy decoding (wa_full.cpp).  The host's per-token work - the reference's logit rules, an ORDERED F32
+// log-sum-exp over 51 865 logits, libm exp for the timestamp range (whisper.cpp:6149-6489) - costs about a third of a
+// decode step and cannot start before the step's logits exist.  So the device predicts the token itself (wa_mega.hip:
+// candidate records under the same rules, merged by the next launch) and decodes it right away; the host derives the
+// token the exact way from the logits meanwhile and compares.  A wrong prediction (rare) costs one step: the launches
+// in flight are discarded and the step is redone with the right token.  Launch k writes output / record / state buffer
+// k & 1 and reads buffer (k - 1) & 1; at most launches k and k + 1 are in flight while the host works on logits k - 1...k.
+// -------------------------------------------------------------------------------------------------
+bool wa_spec_begin(whisper_context & ctx, whisper_state & st, const std::vector<uint32_t> & bits) {
+    if (!st.mega_enabled || bits.size() > (size_t) ctx.model.hp.n_vocab / 32 + 2) return false;
+    if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
+    if (!st.copy_stream) {      // first use on this state
+        for (int b = 0; b < 2; ++b) {
+            if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_spec[b], ((size_t) ctx.model.hp.n_vocab + 16) * sizeof(float)))) return false;
+            if (!WA_HIP_OK(hipEventCreateWithFlags(&st.ev_k[b], hipEventDisableTiming)) || !WA_HIP_OK(hipEventCreateWithFlags(&st.ev_c[b], hipEventDisableTiming))) return false;
+        }
+        if (!WA_HIP_OK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking))) { st.copy_stream = nullptr; return false; }
+    }
+    g_mega_mutex.lock();       // exclusive use of the device's one-launch slot until wa_spec_end
+    (void) hipMemcpyAsync(st.d_mega_smask, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st.stream);
+    return WA_HIP_OK(hipStreamSynchronize(st.stream));
+}
+
+void wa_spec_end(whisper_context &, whisper_state & st) {
+    (void) hipStreamSynchronize(st.stream);
+    (void) hipStreamSynchronize(st.copy_stream);
+    (void) hipMemsetAsync(st.d_mega_smask, 0, ((size_t) st.ctx->model.hp.n_vocab / 32 + 2) * sizeof(uint32_t), st.stream);   // plain steps use no mask
+    (void) hipStreamSynchronize(st.stream);
+    g_mega_mutex.unlock();
+}
+
+bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, int token, const wa_spec_state & after) {
+    wa_mega_args a;
+    if (!mega_args(ctx, st, a, token < 0 ? 0 : token, pos, pos + 1, pos)) return false;       // greedy steady state: cell == position
+    const int b = k & 1;
+    a.logits = b ? st.d_mega_out2 : st.d_mega_out;
+    a.status = (unsigned *) (a.logits + ctx.model.hp.n_vocab);
+    a.spec = token < 0 ? 1 : 0;
+    a.rec_in = st.d_mega_rec[b ^ 1]; a.rec_out = st.d_mega_rec[b];
+    a.ps_in = st.d_mega_ps[b ^ 1];   a.ps_out = st.d_mega_ps[b];
+    a.s_last = after.last; a.s_penult = after.penult; a.s_seek_delta = after.seek_delta; a.s_has_ts = after.has_ts;
+    wa_launch_decode_mega(st.stream, a, a.n_rec);
+    (void) hipEventRecord(st.ev_k[b], st.stream);
+    (void) hipStreamWaitEvent(st.copy_stream, st.ev_k[b], 0);
+    (void) hipMemcpyAsync(st.h_spec[b], a.logits, ((size_t) ctx.model.hp.n_vocab + 2) * sizeof(float), hipMemcpyDeviceToHost, st.copy_stream);
+    return WA_HIP_OK(hipEventRecord(st.ev_c[b], st.copy_stream));
+}
+
+int wa_spec_wait(whisper_context & ctx, whisper_state & st, int k, int * token_used) {
+    const int b = k & 1, n_vocab = ctx.model.hp.n_vocab;
+    const int64_t t0 = wa_time_us();
+    if (!WA_HIP_OK(hipEventSynchronize(st.ev_c[b]))) { st.mega_enabled = false; return -1; }
+    const unsigned status = ((const unsigned *) st.h_spec[b])[n_vocab];
+    if (token_used) *token_used = ((const int *) st.h_spec[b])[n_vocab + 1];
+    st.t_decode_us += wa_time_us() - t0; st.n_decode++;
+    if (status != 0) {
+        wa_spec_drain(ctx, st);
+        (void) hipMemsetAsync(st.d_mega_out + n_vocab, 0, sizeof(unsigned), st.stream);
+        (void) hipMemsetAsync(st.d_mega_out2 + n_vocab, 0, sizeof(unsigned), st.stream);
+        (void) hipStreamSynchronize(st.stream);
+        if (status == WA_MEGA_REDO) return 1;
+        WA_WARN("%s: one-launch decode step gave up at hand-off %u - using the launch sequence from now on\n", __func__, status);
+        st.mega_enabled = false;
+        return -1;
+    }
+    st.logits.resize(n_vocab);
+    memcpy(st.logits.data(), st.h_spec[b], (size_t) n_vocab * sizeof(float));
+    return 0;
+}
+
+void wa_spec_drain(whisper_context &, whisper_state & st) {
+    (void) hipStreamSynchronize(st.stream);
+    (void) hipStreamSynchronize(st.copy_stream);
 }
 
 bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads, ggml_abort_callback abort_cb,

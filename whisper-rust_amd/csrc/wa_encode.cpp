@@ -90,6 +90,11 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
             if (!dev_alloc(st.d_mega_cgr, (size_t) hp.n_text_layer * Ht * WA_MEGA_CGR)) return false;
             if (!dev_alloc(st.d_mega_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * 2 * dt) || !dev_alloc(st.d_mega_out, (size_t) hp.n_vocab + 64)) return false;
             st.d_mega_status = (unsigned *) (st.d_mega_out + hp.n_vocab);
+            if (!dev_alloc(st.d_mega_out2, (size_t) hp.n_vocab + 64) || !dev_alloc(st.d_mega_smask, (size_t) hp.n_vocab / 32 + 2)) return false;
+            for (int b = 0; b < 2; ++b)
+                if (!dev_alloc(st.d_mega_rec[b], (size_t) 512 * 8) || !dev_alloc(st.d_mega_ps[b], 8)) return false;
+            // (the copy stream, events and pinned buffers of the host overlap are created on first use, wa_spec_begin: a state that
+            //  only ever runs inside whisper_amd_full_batch keeps ONE stream - extra streams cost the concurrent chunks their overlap)
         }
     }
     if (!dev_alloc(st.d_att_partial, (size_t) 512 * 32 * 64) || !dev_alloc(st.d_att_pleft, (size_t) 512 * 32)) return false;
@@ -120,6 +125,14 @@ void wa_state_release(whisper_state & st) {
     dev_free(st.d_dx); dev_free(st.d_dxn); dev_free(st.d_dqkv); dev_free(st.d_dao); dev_free(st.d_dff); dev_free(st.d_dq);
     if (st.dec_graph) { (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr; }
     dev_free(st.d_mega_gr); dev_free(st.d_mega_cgr); dev_free(st.d_mega_out); st.d_mega_status = nullptr;
+    dev_free(st.d_mega_out2); dev_free(st.d_mega_smask);
+    for (int b = 0; b < 2; ++b) {
+        dev_free(st.d_mega_rec[b]); dev_free(st.d_mega_ps[b]);
+        if (st.h_spec[b]) { (void) hipHostFree(st.h_spec[b]); st.h_spec[b] = nullptr; }
+        if (st.ev_k[b]) { (void) hipEventDestroy(st.ev_k[b]); st.ev_k[b] = nullptr; }
+        if (st.ev_c[b]) { (void) hipEventDestroy(st.ev_c[b]); st.ev_c[b] = nullptr; }
+    }
+    if (st.copy_stream) { (void) hipStreamDestroy(st.copy_stream); st.copy_stream = nullptr; }
     dev_free(st.d_dyn); dev_free(st.d_att_partial); dev_free(st.d_att_pleft); dev_free(st.d_im2col); dev_free(st.d_logits); dev_free(st.d_aheads_qk);
     if (st.h_stage_i32)     { (void) hipHostFree(st.h_stage_i32);     st.h_stage_i32 = nullptr; }
     if (st.h_stage_mask)    { (void) hipHostFree(st.h_stage_mask);    st.h_stage_mask = nullptr; }

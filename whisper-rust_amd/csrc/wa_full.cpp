@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <regex>
 #include <immintrin.h>
 
@@ -121,6 +122,19 @@ struct runner {
             }
             for (const char * t : { " -", " '" }) { auto it = vocab.token_to_id.find(t); if (it != vocab.token_to_id.end()) suppress_ids.push_back(it->second); }
         }
+    }
+
+    // the call-constant part of the logit rules below as a bit set, for the device's next-token prediction (wa_spec_*)
+    std::vector<uint32_t> suppress_bits() const {
+        std::vector<uint32_t> b((size_t) n_vocab / 32 + 1, 0u);
+        auto set = [&](int i) { if (i >= 0 && i < n_vocab) b[i >> 5] |= 1u << (i & 31); };
+        set(vocab.token_not); set(vocab.token_sot); set(vocab.token_nosp);
+        if (!p.tdrz_enable) set(vocab.token_solm);
+        set(vocab.token_translate); set(vocab.token_transcribe); set(vocab.token_prev);
+        for (int i = 0; i < 100; ++i) set(vocab.token_sot + 1 + i);
+        if (p.no_timestamps) for (int i = vocab.token_beg; i < n_vocab; ++i) set(i);
+        for (int id : suppress_ids) set(id);
+        return b;
     }
 
     // ---- whisper_process_logits (whisper.cpp:6149-6417) ----
@@ -428,6 +442,24 @@ int runner::run(const float * samples, int n_samples) {
                 st->t_sample_us += wa_time_us() - ts;
             }
 
+            // Greedy arg-max decoding with one decoder on the one-launch step: overlap the host's logit rules with the NEXT
+            // decode step, which runs on the device's own prediction of the token (wa_decode.cpp wa_spec_*); every token is
+            // still derived here from the logits with the reference's rules, a wrong prediction only costs a redone step.
+            struct overlap_guard {
+                whisper_context * c; whisper_state * s; bool on = false;
+                ~overlap_guard() { if (on) wa_spec_end(*c, *s); }
+            } ov { ctx, st };
+            int ov_launched = 0;            // launches issued so far: L_0 .. L_{ov_launched-1}; L_k decodes the k-th sampled token
+            {
+                const char * e = getenv("WHISPER_AMD_NO_OVERLAP");
+                const int P = (int) prompt.size();
+                const auto & kvc = st->kv_self;
+                const bool seq_cells = wa_kv_cell_max(kvc) == P && P < (int) kvc.size && kvc.cells[P].pos < 0;
+                if (!(e && e[0] == '1') && p.strategy == WHISPER_SAMPLING_GREEDY && n_dec == 1 && t_cur < 1e-6f && !p.logits_filter_callback &&
+                    st->mega_enabled && ctx->model.n_loaded > 0 && seq_cells)
+                    ov.on = wa_spec_begin(*ctx, *st, suppress_bits());
+            }
+
             for (int i = 0, n_max = n_text_ctx / 2 - 4; i < n_max; ++i) {
                 const int64_t ts0 = wa_time_us();
                 if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) for (auto & bc : bc_per_dec) bc.clear();
@@ -529,7 +561,39 @@ int runner::run(const float * samples, int n_samples) {
                         b.logits.push_back(1);
                         b.n_tokens++;
                     }
-                    if (!wa_decode(*ctx, *st, b, false, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -9; }
+                    bool have_logits = false;
+                    if (ov.on) {
+                        auto & dec = st->decoders[0];
+                        const auto & toks = dec.sequence.tokens;
+                        auto state_after = [&](int k) {     // sampling state after the k-th token, as process_logits will see it
+                            wa_spec_state s0; s0.last = toks[k].id; s0.penult = k > 0 ? toks[k - 1].id : -1; s0.seek_delta = dec.seek_delta; s0.has_ts = dec.has_ts ? 1 : 0;
+                            return s0;
+                        };
+                        const wa_spec_state none = { 0, -1, 0, 0 };
+                        auto can_launch = [&](int k) { return k < n_max && n_past - i + k < n_text_ctx; };
+                        bool ok = true;
+                        if (ov_launched <= i) { ok = wa_spec_launch(*ctx, *st, i, n_past, toks[i].id, state_after(i)); ov_launched = i + 1; }
+                        if (ok && ov_launched == i + 1 && can_launch(i + 1)) { ok = wa_spec_launch(*ctx, *st, i + 1, n_past + 1, -1, none); ov_launched = i + 2; }
+                        int used = -1, rc = ok ? wa_spec_wait(*ctx, *st, i, &used) : -1;
+                        if (rc == 0 && used != toks[i].id) {            // the device decoded another token than the rules give: redo this step
+                            st->n_spec_miss++;
+                            wa_spec_drain(*ctx, *st);
+                            ok = wa_spec_launch(*ctx, *st, i, n_past, toks[i].id, state_after(i)); ov_launched = i + 1;
+                            if (ok && can_launch(i + 1)) { ok = wa_spec_launch(*ctx, *st, i + 1, n_past + 1, -1, none); ov_launched = i + 2; }
+                            rc = ok ? wa_spec_wait(*ctx, *st, i, &used) : -1;
+                        } else if (rc == 0 && i > 0) st->n_spec_ok++;
+                        if (rc == 0) {
+                            if (!wa_kv_find_slot(st->kv_self, b) || (int) st->kv_self.head != n_past) { WA_ERROR("%s: KV cells out of step with the overlapped decode\n", __func__); return -9; }
+                            st->kv_self.n = std::min(st->kv_self.size, (uint32_t) std::max(1, wa_kv_cell_max(st->kv_self)));
+                            if (p.abort_callback && p.abort_callback(p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -9; }
+                            have_logits = true;
+                        } else {        // the one-launch step is not available for this token (or any more): finish the window the plain way
+                            wa_spec_drain(*ctx, *st);
+                            wa_spec_end(*ctx, *st);
+                            ov.on = false;
+                        }
+                    }
+                    if (!have_logits && !wa_decode(*ctx, *st, b, false, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -9; }
                     const int64_t ts1 = wa_time_us();
                     for (int j = 0; j < n_dec; ++j) {
                         auto & dec = st->decoders[j];

@@ -235,6 +235,16 @@ struct whisper_state {
     unsigned * d_mega_status = nullptr;   // = d_mega_out + n_vocab
     unsigned mega_seq = 0;
     bool mega_enabled = false;
+    // host overlap (wa_decode.cpp wa_spec_*): the device predicts the next token and decodes it while the host still
+    // applies the reference's sampling rules to the previous logits; two output / record / state buffers alternate
+    float * d_mega_out2 = nullptr;                 // second logits + status + token buffer
+    unsigned * d_mega_rec[2] = { nullptr, nullptr };   // candidate records [n_workgroups][8]
+    int * d_mega_ps[2] = { nullptr, nullptr };     // sampling state after a launch's token
+    unsigned * d_mega_smask = nullptr;             // [n_vocab / 32 + 1] per-call suppression bits
+    float * h_spec[2] = { nullptr, nullptr };      // pinned [n_vocab + 16]
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_k[2] = { nullptr, nullptr }, ev_c[2] = { nullptr, nullptr };
+    int n_spec_ok = 0, n_spec_miss = 0;
 
     // pinned host staging
     int32_t * h_stage_i32 = nullptr; int8_t * h_stage_mask = nullptr; size_t h_mask_cap = 0;
@@ -268,6 +278,13 @@ bool wa_mel_set    (whisper_context & ctx, whisper_state & st, const float * dat
 bool wa_encode     (whisper_context & ctx, whisper_state & st, int mel_offset, ggml_abort_callback cb, void * cb_data);
 bool wa_decode     (whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads,
                     ggml_abort_callback cb, void * cb_data);                         // wa_decode.cpp
+// host-overlapped greedy decoding on the one-launch step (wa_decode.cpp); launch k decodes position pos0 + k
+struct wa_spec_state { int last, penult, seek_delta, has_ts; };
+bool wa_spec_begin (whisper_context & ctx, whisper_state & st, const std::vector<uint32_t> & suppress_bits);
+bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, int token /* < 0: the device's own pick */, const wa_spec_state & after);
+int  wa_spec_wait  (whisper_context & ctx, whisper_state & st, int k, int * token_used);   // 0 ok (logits in st.logits row 0), 1 redo, -1 gave up
+void wa_spec_drain (whisper_context & ctx, whisper_state & st);
+void wa_spec_end   (whisper_context & ctx, whisper_state & st);
 bool wa_state_alloc(whisper_context & ctx, whisper_state & st);
 void wa_state_release(whisper_state & st);
 bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells);

@@ -32,6 +32,15 @@ struct wa_mega_args {
     float * dbg;                                                                // optional [layer][head][2][1536]: cross-attention scores, probabilities
     // launch
     int token, pos, n_kv, kv_head; unsigned seq; float kq_scale;
+    // next-token prediction (host overlap, wa_decode.cpp: wa_spec_*).  Every launch leaves per-workgroup candidate records
+    // of its logits under the reference's logit rules (whisper.cpp:6149-6333, approximated: the host verifies every token);
+    // with spec != 0 the launch takes its input token from the records and state of the previous launch instead of `token`.
+    int spec;
+    const unsigned * rec_in; unsigned * rec_out; int n_rec;          // [n_workgroups][8]: {max text logit, id, max timestamp logit, id, sum exp(ts - max ts)}
+    const int * ps_in; int * ps_out;                                 // {last token, token before it (-1: none), seek_delta, has_ts}
+    const unsigned * smask;                                          // bit i set: token i is suppressed for the whole call
+    int token_beg, token_eot;
+    int s_last, s_penult, s_seek_delta, s_has_ts;                    // spec == 0: the state after `token`, from the host
 };
 
 #define WA_MEGA_EDGES 8

@@ -106,7 +106,7 @@ __device__ __forceinline__ void mg_ln_params(float (&gw)[NPL], float (&gb)[NPL],
 // front of the polling loads: measured 5 us per LayerNorm phase)
 template <int NPL>
 __device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge /* null: embeddings */, const float (&gw)[NPL], const float (&gb)[NPL],
-                                             int lane, float * xf, wa_f16 * xin, unsigned code, int tslot = -1) {
+                                             int lane, float * xf, wa_f16 * xin, unsigned code, int tslot = -1, int token = 0) {
     const int d = A->d;
     float xv[NPL];
     if (edge) {
@@ -116,7 +116,7 @@ __device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge
 #pragma unroll
         for (int k = 0; k < NPL; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
     } else {                                      // k_dec_embed: token embedding + positional embedding
-        const gch te = (gch) A->te + (size_t) A->token * d;
+        const gch te = (gch) A->te + (size_t) token * d;
         const gcf pe = (gcf) A->pe + (size_t) A->pos * d;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? h2f(te[i]) + pe[i] : 0.0f; }
@@ -299,6 +299,60 @@ __device__ __forceinline__ unsigned mg_pub_h2(gu64 * edge, unsigned seq, bool va
 }
 
 // -------------------------------------------------------------------------------------------------
+// next-token prediction.  mg_pick (wave 0 of every workgroup, at the start): the input token of this launch - given, or
+// (spec) merged from the candidate records the previous launch left - and the sampling state after it, into LDS.
+// mg_final classifies every logit by that state and leaves this launch's records.  Device arithmetic here is a
+// prediction only (fast exp, any order): the host re-derives every token from the logits with the reference's rules.
+// -------------------------------------------------------------------------------------------------
+#define MG_ATT_SMEM(maxkv) (8 * 8 + (maxkv) * 4 + ((maxkv) / 8) * 4 + 32 * 64 * 4 + 8 * 4 + 16 + (maxkv) * 2 + 64 * 2 + 64)      // LDS of the attention scratch (mg_att_carve)
+#define MG_PICK_OFF ((((size_t) WA_MEGA_MAX_KV * 64 * 2 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_KV)) + 255) & ~(size_t) 255)   // behind every role's LDS
+#define MG_PICK_BYTES 512
+struct mg_best { float v; int i; };
+__device__ __forceinline__ void mg_best_merge(mg_best & a, float v, int i) { if (v > a.v || (v == a.v && i < a.i)) { a.v = v; a.i = i; } }
+__device__ __forceinline__ void mg_best_wave(mg_best & a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float v = __shfl_xor(a.v, o, WAVE); const int i = __shfl_xor(a.i, o, WAVE); mg_best_merge(a, v, i); }
+}
+__device__ __forceinline__ int mg_decide(const mg_best & bt, const mg_best & bs, float s_ts, int token_beg) {
+    // whisper.cpp:6309-6333: timestamp mass above every text token => a timestamp; else the arg-max of everything allowed
+    if (!(bs.v > -INFINITY)) return bt.v > -INFINITY ? bt.i : 0;
+    if (!(bt.v > -INFINITY)) return bs.i;
+    if (__logf(s_ts) + bs.v > bt.v) return bs.i;
+    return bs.v > bt.v ? bs.i : bt.i;
+}
+__device__ __forceinline__ void mg_pick(mg_kargs A, int lane, int * pk) {
+    int token = A->token, last = A->s_last, penult = A->s_penult, seek_delta = A->s_seek_delta, has_ts = A->s_has_ts;
+    if (A->spec) {
+        const GAS int * ps = (const GAS int *) A->ps_in;
+        const GAS unsigned * rec = (const GAS unsigned *) A->rec_in;
+        penult = ps[0]; seek_delta = ps[2]; has_ts = ps[3];
+        mg_best bt = { -INFINITY, 0x7fffffff }, bs = { -INFINITY, 0x7fffffff };
+        for (int g = lane; g < A->n_rec; g += 64) {
+            mg_best_merge(bt, __uint_as_float(rec[g * 8 + 0]), (int) rec[g * 8 + 1]);
+            mg_best_merge(bs, __uint_as_float(rec[g * 8 + 2]), (int) rec[g * 8 + 3]);
+        }
+        mg_best_wave(bt); mg_best_wave(bs);
+        float s = 0.0f;
+        for (int g = lane; g < A->n_rec; g += 64) {
+            const float m = __uint_as_float(rec[g * 8 + 2]);
+            if (m > -INFINITY) s += __uint_as_float(rec[g * 8 + 4]) * __expf(m - bs.v);
+        }
+        s = wave_sum(s);
+        token = mg_decide(bt, bs, s, A->token_beg);
+        last = token;
+        if (token > A->token_beg) { seek_delta = 2 * (token - A->token_beg); has_ts = 1; }
+    }
+    if (lane == 0) {
+        pk[0] = token; pk[1] = last; pk[2] = penult; pk[3] = seek_delta; pk[4] = has_ts;
+        if (blockIdx.x == 0) {
+            GAS int * po = (GAS int *) A->ps_out;
+            po[0] = last; po[1] = penult; po[2] = seek_delta; po[3] = has_ts;
+            ((GAS int *) A->logits)[A->n_vocab + 1] = token;          // behind the logits and the status word: the token this launch decoded
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // final LayerNorm + logits = token_embedding . x (whisper.cpp:2820-2835): every workgroup, every wave
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void mg_prefetch_logits(mg_kargs A, unsigned (&pf)[96], bool & have_pf, int lane, int wave) {
@@ -314,18 +368,63 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
     float  * xf  = (float *) smem;
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);
     const int d = A->d, nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab;
-    if (wave == 0) mg_gather_ln<NPL>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, lane, xf, xin, 3000u, blockIdx.x == 0 ? (A->n_layer * 8) * 8 : -1);
+    if (wave == 0) mg_gather_ln<NPL>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, lane, xf, xin, 3000u, blockIdx.x == 0 ? (A->n_layer * 8) * 8 : -1,
+                                     ((const int *) (smem + MG_PICK_OFF))[0]);
     mg_barrier();
     const int NG = (n_vocab + 7) >> 3;
     GAS float * logits = (GAS float *) A->logits;
+    // sampling state after this launch's token -> which logits the next pick may choose (whisper.cpp:6264-6302)
+    const int * pk = (const int *) (smem + MG_PICK_OFF);
+    const int beg = A->token_beg, eot = A->token_eot;
+    const int st_last = pk[1], st_penult = pk[2], st_seek = pk[3], st_has = pk[4];
+    const bool last_ts = st_last >= beg, penult_ts = st_penult < 0 || st_penult >= beg;
+    const bool no_ts = last_ts && penult_ts, no_text = last_ts && !penult_ts;
+    const int ts_min = st_has ? beg + st_seek / 2 : beg;
+    const GAS unsigned * smask = (const GAS unsigned *) A->smask;
+    mg_best bt = { -INFINITY, 0x7fffffff }, bs = { -INFINITY, 0x7fffffff };
+    float s_ts = 0.0f;
     for (int j = 0;; ++j) {
         const int g = wg + nwg * (wave + MG_NW * j);
         if (g >= NG) break;
         const int row = g * 8 + (lane >> 3);
         const bool valid = row < n_vocab;
+        const unsigned mw = valid && (lane & 7) == 0 ? smask[row >> 5] : 0xffffffffu;
         const gch wrow = (gch) A->te + (size_t) (valid ? row : 0) * d + 4 * (lane & 7);
         const float r = mg_dot8(pf, wrow, valid, d >> 5, xin, lane & 7, j == 0 && have_pf);
-        if (valid && (lane & 7) == 0) logits[row] = r;
+        if (valid && (lane & 7) == 0) {
+            logits[row] = r;
+            if (!((mw >> (row & 31)) & 1u)) {
+                if (row >= beg) {
+                    if (!no_ts && row >= ts_min) {
+                        if (r > bs.v) { s_ts = s_ts * __expf(bs.v - r) + 1.0f; bs.v = r; bs.i = row; }
+                        else s_ts += __expf(r - bs.v);
+                    }
+                } else if (!(no_text && row < eot)) mg_best_merge(bt, r, row);
+            }
+        }
+    }
+    {   // this workgroup's record
+        unsigned * rb = (unsigned *) (smem + MG_PICK_OFF + 64);
+        const float m_loc = bs.v;
+        mg_best_wave(bt); mg_best_wave(bs);
+        float sw = m_loc > -INFINITY ? s_ts * __expf(m_loc - bs.v) : 0.0f;
+        sw = wave_sum(sw);
+        if (lane == 0) { rb[wave * 8 + 0] = __float_as_uint(bt.v); rb[wave * 8 + 1] = (unsigned) bt.i; rb[wave * 8 + 2] = __float_as_uint(bs.v);
+                         rb[wave * 8 + 3] = (unsigned) bs.i; rb[wave * 8 + 4] = __float_as_uint(sw); }
+        mg_barrier();
+        if (wave == 0) {
+            mg_best t2 = { -INFINITY, 0x7fffffff }, s2 = { -INFINITY, 0x7fffffff };
+            float sl = 0.0f, ml = -INFINITY;
+            if (lane < MG_NW) { t2.v = __uint_as_float(rb[lane * 8 + 0]); t2.i = (int) rb[lane * 8 + 1]; s2.v = __uint_as_float(rb[lane * 8 + 2]); s2.i = (int) rb[lane * 8 + 3];
+                                sl = __uint_as_float(rb[lane * 8 + 4]); ml = s2.v; }
+            mg_best_wave(t2); mg_best_wave(s2);
+            float sg = ml > -INFINITY ? sl * __expf(ml - s2.v) : 0.0f;
+            sg = wave_sum(sg);
+            if (lane == 0) {
+                GAS unsigned * ro = (GAS unsigned *) A->rec_out + (size_t) wg * 8;
+                ro[0] = __float_as_uint(t2.v); ro[1] = (unsigned) t2.i; ro[2] = __float_as_uint(s2.v); ro[3] = (unsigned) s2.i; ro[4] = __float_as_uint(sg);
+            }
+        }
     }
     mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, (A->n_layer * 8) * 8 + 3, mg_now());
 }
@@ -360,7 +459,8 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     const int kv_head = A->kv_head;
 
     float gw[NPL], gb[NPL];          // wave 0: gamma / beta of its next LayerNorm
-    if (wave == 0) mg_ln_params<NPL>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, lane);
+    int * pk = (int *) (smem + MG_PICK_OFF);
+    if (wave == 0) { mg_ln_params<NPL>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, lane); mg_pick(A, lane, pk); }
     mg_task t; t.valid = false; t.row = 0; t.wrow = nullptr; t.bias = 0.f; t.scale = 1.f;
     if (wave == 1 || wave == 2) t = mg_task8(pf, Ly[0].qkv_w, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
     else if (wave == 3)         t = mg_task8(pf, Ly[0].out_w, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -372,7 +472,7 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         // ---------------- P1: LayerNorm + q|k|v ----------------
         if (wave == 0) {
-            mg_gather_ln<NPL>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, lane, xf, xin, 100u + l, wg == 0 ? (l * 8 + 0) * 8 : -1);
+            mg_gather_ln<NPL>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, lane, xf, xin, 100u + l, wg == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
             mg_ln_params<NPL>(gw, gb, Y.ln2_w, Y.ln2_b, d, lane);
         }
         mg_barrier();
@@ -498,7 +598,6 @@ __device__ __forceinline__ mg_att_smem mg_att_carve(unsigned char * base, int ma
     m.qs   = (wa_f16 *) base;
     return m;
 }
-#define MG_ATT_SMEM(maxkv) (8 * 8 + (maxkv) * 4 + ((maxkv) / 8) * 4 + 32 * 64 * 4 + 8 * 4 + 16 + (maxkv) * 2 + 64 * 2 + 64)
 
 __device__ __forceinline__ void mg_softmax(const mg_att_smem & M, int n_kv, float lmax, int tid, int lane, int wave, GAS float * dbg = nullptr) {
     float * sc = M.sc;
@@ -599,6 +698,7 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
     const mg_att_smem M = mg_att_carve(smem + (size_t) WA_MEGA_MAX_KV * 64 * 2 * 2, WA_MEGA_MAX_KV);
     const int d = A->d, n_kv = A->n_kv, kv_head = A->kv_head, L = A->n_layer;
     const int a = tid & 3, kslot = tid >> 2;
+    if (wave == 0) mg_pick(A, lane, (int *) (smem + MG_PICK_OFF));
     for (int l = 0; l < L; ++l) {
         {   // cells of earlier tokens -> LDS (row kv_head is stale here and replaced below)
             const gch kc = (gch) A->kv_k + (size_t) l * A->kv_layer_stride + h * 64;
@@ -717,6 +817,7 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
     const float kq_scale = A->kq_scale;
     const int a = tid & 3, ks = tid >> 2;
     const int np = T & ~31, nsteps = np >> 5, nl = T - np, n8 = T & ~7, ng = n8 >> 3;
+    if (wave == 0) mg_pick(A, lane, (int *) (smem + MG_PICK_OFF));
     for (int l = 0; l < L; ++l) {
         gu64 * X = (gu64 *) A->cross_gr + ((size_t) l * H + h) * MG_CGR;
         const gch kp = (gch) A->cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
@@ -865,7 +966,8 @@ size_t wa_mega_lds_bytes() {
     const size_t s_gemv  = (size_t) WA_MEGA_MAX_D * 4 + (size_t) 4 * WA_MEGA_MAX_D * 2;
     size_t m = s_self > s_cross ? s_self : s_cross;
     m = m > s_gemv ? m : s_gemv;
-    return (m + 255) & ~(size_t) 255;
+    if (((m + 255) & ~(size_t) 255) != MG_PICK_OFF) abort();      // the pick area sits right behind the largest role
+    return MG_PICK_OFF + MG_PICK_BYTES;
 }
 
 void wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg) {
