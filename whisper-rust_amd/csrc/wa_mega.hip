@@ -37,7 +37,7 @@ __device__ __forceinline__ mg_kargs mg_uniform(mg_kargs p) {
 
 #define MG_THREADS 512
 #define MG_NW (MG_THREADS / 64)
-#define MG_NPL 20                 // LayerNorm elements per lane of one wave: d <= 1280
+#define MG_NP3 7                  // LayerNorm elements per lane of one of the three gather waves: d <= 1344
 #define MG_SPIN_LIMIT 300000u     // polls (~0.5 us each) before a hand-off is declared dead
 
 enum { E_QKV = 0, E_AO, E_X1, E_QC, E_AO2, E_X2, E_HF, E_X3 };
@@ -90,72 +90,89 @@ __device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int la
 }
 
 // -------------------------------------------------------------------------------------------------
-// wave 0 of a workgroup: obtain the F32 residual row (from granules, or from the embeddings for layer 0), keep it in
-// LDS (xf) and write LayerNorm(row) as F16 into xin.  ops.cpp:3225-3242 semantics, as k_layernorm_exact.
+// LayerNorm phases.  THREE waves (0, 6, 7 = slots q 0..2; every other wave passes q < 0 and only keeps the barriers) each
+// obtain a third of the F32 residual row - from granules, or from the embeddings for layer 0 -, keep it in LDS (xf) and
+// write their third of LayerNorm(row) as F16 into xin.  ops.cpp:3225-3242 semantics as k_layernorm_exact: F64 sums in an
+// arbitrary order, accepted when certified order-independent, else redone in index order (by each slot, identically).
+// A single wave polling all d granules took ~2 us per pass and 1.6 us for the arithmetic; a third each is faster on both.
 // -------------------------------------------------------------------------------------------------
-template <int NPL>
-__device__ __forceinline__ void mg_ln_params(float (&gw)[NPL], float (&gb)[NPL], const float * lw, const float * lb, int d, int lane) {
+__device__ __forceinline__ int mg_ln_seg(int d) { return ((d + 191) / 192) * 64; }
+template <int NP3>
+__device__ __forceinline__ void mg_ln_params(float (&gw)[NP3], float (&gb)[NP3], const float * lw, const float * lb, int d, int q, int lane) {
+    const int seg = mg_ln_seg(d), i0 = q * seg, i1 = min(d, i0 + seg);
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) {
-        const int i = lane + 64 * k;
-        const bool ok = i < d;
+    for (int k = 0; k < NP3; ++k) {
+        const int i = i0 + lane + 64 * k;
+        const bool ok = q >= 0 && i < i1;
         gw[k] = ok ? ((gcf) lw)[i] : 0.0f; gb[k] = ok ? ((gcf) lb)[i] : 0.0f;
     }
 }
 // gw / gb: gamma and beta of THIS LayerNorm, loaded one phase ahead (a load issued here would sit, with its pointer fetch, in
 // front of the polling loads: measured 5 us per LayerNorm phase)
-template <int NPL>
-__device__ __forceinline__ void mg_gather_ln(mg_kargs A, mg_ctl & c, gu64 * edge /* null: embeddings */, const float (&gw)[NPL], const float (&gb)[NPL],
-                                             int lane, float * xf, wa_f16 * xin, unsigned code, int tslot = -1, int token = 0) {
-    const int d = A->d;
-    float xv[NPL];
-    if (edge) {
-        unsigned v[NPL];
-        const unsigned sp = mg_sweep<NPL>(edge, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
-        if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
+template <int NP3>
+__device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* null: embeddings */, const float (&gw)[NP3], const float (&gb)[NP3], int q,
+                                       int lane, float * xf, wa_f16 * xin, double * lnred, unsigned code, int tslot = -1, int token = 0) {
+    const int d = A->d, seg = mg_ln_seg(d), i0 = q * seg, i1 = min(d, i0 + seg);
+    float xv[NP3];
+    if (q >= 0) {
+        if (edge) {
+            unsigned v[NP3];
+            const unsigned sp = mg_sweep<NP3>(edge, [&](int k) { const int i = i0 + lane + 64 * k; return i < i1 ? i : -1; }, c, lane, v, code);
+            if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
-    } else {                                      // k_dec_embed: token embedding + positional embedding
-        const gch te = (gch) A->te + (size_t) token * d;
-        const gcf pe = (gcf) A->pe + (size_t) A->pos * d;
+            for (int k = 0; k < NP3; ++k) xv[k] = (i0 + lane + 64 * k < i1) ? __uint_as_float(v[k]) : 0.0f;
+        } else {                                      // k_dec_embed: token embedding + positional embedding
+            const gch te = (gch) A->te + (size_t) token * d;
+            const gcf pe = (gcf) A->pe + (size_t) A->pos * d;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? h2f(te[i]) + pe[i] : 0.0f; }
-    }
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) { const int i = lane + 64 * k; if (i < d) xf[i] = xv[k]; }
-    double s = 0.0, a = 0.0;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
-    s = wave_sum_d(s); a = wave_sum_d(a);
-    float mean;
-    if (!wa_sum_certain(s, a, d, mean)) {
-        if (lane == 0) s = wa_seq_sum_lds(xf, d, false, 0.0f);
-        s = __shfl(s, 0, WAVE);
-        mean = (float) (s / (double) d);
-    }
-    double s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
-    s2 = wave_sum_d(s2);
-    float variance;
-    if (!wa_sum_certain(s2, s2, d, variance)) {
-        if (lane == 0) s2 = wa_seq_sum_lds(xf, d, true, mean);
-        s2 = __shfl(s2, 0, WAVE);
-        variance = (float) (s2 / (double) d);
-    }
-    const float scale = 1.0f / sqrtf(variance + A->eps);
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) {
-        const int i = lane + 64 * k;
-        if (i < d) {
-            float y = xv[k] - mean;
-            y = y * scale;
-            y = y * gw[k];
-            y = y + gb[k];
-            xin[i] = f2h(y);
+            for (int k = 0; k < NP3; ++k) { const int i = i0 + lane + 64 * k; xv[k] = i < i1 ? h2f(te[i]) + pe[i] : 0.0f; }
         }
+        double s = 0.0, a = 0.0;
+#pragma unroll
+        for (int k = 0; k < NP3; ++k) { const int i = i0 + lane + 64 * k; if (i < i1) xf[i] = xv[k]; s += (double) xv[k]; a += (double) fabsf(xv[k]); }
+        s = wave_sum_d(s); a = wave_sum_d(a);
+        if (lane == 0) { lnred[q] = s; lnred[3 + q] = a; }
     }
-    if (tslot >= 0) mg_trace(A, lane == 0, tslot + 2, mg_now());
+    mg_barrier();
+    float mean = 0.0f;
+    if (q >= 0) {
+        double s = (lnred[0] + lnred[1]) + lnred[2];
+        const double a = (lnred[3] + lnred[4]) + lnred[5];
+        if (!wa_sum_certain(s, a, d, mean)) {
+            if (lane == 0) s = wa_seq_sum_lds(xf, d, false, 0.0f);
+            s = __shfl(s, 0, WAVE);
+            mean = (float) (s / (double) d);
+        }
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NP3; ++k) if (i0 + lane + 64 * k < i1) { const float t = xv[k] - mean; s2 += (double) (t * t); }
+        s2 = wave_sum_d(s2);
+        if (lane == 0) lnred[6 + q] = s2;
+    }
+    mg_barrier();
+    if (q >= 0) {
+        double s2 = (lnred[6] + lnred[7]) + lnred[8];
+        float variance;
+        if (!wa_sum_certain(s2, s2, d, variance)) {
+            if (lane == 0) s2 = wa_seq_sum_lds(xf, d, true, mean);
+            s2 = __shfl(s2, 0, WAVE);
+            variance = (float) (s2 / (double) d);
+        }
+        const float scale = 1.0f / sqrtf(variance + A->eps);
+#pragma unroll
+        for (int k = 0; k < NP3; ++k) {
+            const int i = i0 + lane + 64 * k;
+            if (i < i1) {
+                float y = xv[k] - mean;
+                y = y * scale;
+                y = y * gw[k];
+                y = y + gb[k];
+                xin[i] = f2h(y);
+            }
+        }
+        if (tslot >= 0) mg_trace(A, lane == 0, tslot + 2, mg_now());
+    }
+    mg_barrier();
 }
 
 // wave(s): copy the packed-F16 granules [i0, i1) (two halfs each) into LDS once they are all valid
@@ -175,7 +192,9 @@ __device__ __forceinline__ void mg_gather_h2(mg_ctl & c, gu64 * edge, int i0, in
 //   LPR 8 : lane u owns elements 4u..4u+3 of every step (8-byte loads);  result in lanes with u == 0
 //   LPR 16: lane u owns elements 2u, 2u+1 (4-byte loads; long rows, few of them); result in lanes with u == 0
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mg_pf8(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, int s0) {
+template <int NS = 0>
+__device__ __forceinline__ void mg_pf8(unsigned (&pf)[96], gch wrow, bool valid, int nsteps_rt, int s0) {
+    const int nsteps = NS > 0 ? NS : nsteps_rt;
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
         if (s0 + 4 * c < nsteps) {
@@ -187,10 +206,12 @@ __device__ __forceinline__ void mg_pf8(unsigned (&pf)[96], gch wrow, bool valid,
         }
     }
 }
-__device__ __forceinline__ float mg_dot8(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, const wa_f16 * xin, int u, bool have_first) {
+template <int NS = 0>
+__device__ __forceinline__ float mg_dot8(unsigned (&pf)[96], gch wrow, bool valid, int nsteps_rt, const wa_f16 * xin, int u, bool have_first) {
+    const int nsteps = NS > 0 ? NS : nsteps_rt;
     float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
     for (int s0 = 0; s0 < nsteps; s0 += 48) {
-        if (s0 > 0 || !have_first) mg_pf8(pf, wrow, valid, nsteps, s0);
+        if (s0 > 0 || !have_first) mg_pf8<NS>(pf, wrow, valid, nsteps, s0);
 #pragma unroll
         for (int c = 0; c < 12; ++c) {
             if (s0 + 4 * c < nsteps) {
@@ -218,7 +239,9 @@ __device__ __forceinline__ float mg_dot8(unsigned (&pf)[96], gch wrow, bool vali
     }
     return (t[0] + t[1]) + (t[2] + t[3]);
 }
-__device__ __forceinline__ void mg_pf16(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, int s0) {
+template <int NS = 0>
+__device__ __forceinline__ void mg_pf16(unsigned (&pf)[96], gch wrow, bool valid, int nsteps_rt, int s0) {
+    const int nsteps = NS > 0 ? NS : nsteps_rt;
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
         if (s0 + 8 * c < nsteps) {
@@ -230,10 +253,12 @@ __device__ __forceinline__ void mg_pf16(unsigned (&pf)[96], gch wrow, bool valid
         }
     }
 }
-__device__ __forceinline__ float mg_dot16(unsigned (&pf)[96], gch wrow, bool valid, int nsteps, const wa_f16 * xin, int u, bool have_first) {
+template <int NS = 0>
+__device__ __forceinline__ float mg_dot16(unsigned (&pf)[96], gch wrow, bool valid, int nsteps_rt, const wa_f16 * xin, int u, bool have_first) {
+    const int nsteps = NS > 0 ? NS : nsteps_rt;
     float acc[2] = { 0.0f, 0.0f };
     for (int s0 = 0; s0 < nsteps; s0 += 96) {
-        if (s0 > 0 || !have_first) mg_pf16(pf, wrow, valid, nsteps, s0);
+        if (s0 > 0 || !have_first) mg_pf16<NS>(pf, wrow, valid, nsteps, s0);
 #pragma unroll
         for (int c = 0; c < 12; ++c) {
             if (s0 + 8 * c < nsteps) {
@@ -265,6 +290,7 @@ __device__ __forceinline__ int mg_rpw(int N, int nG) { const int r = (N + nG - 1
 
 struct mg_task { gch wrow; bool valid; int row; float bias, scale; };
 
+template <int NS = 0>
 __device__ __forceinline__ mg_task mg_task8(unsigned (&pf)[96], const wa_f16 * W, const float * bias, const float * scale, int N, int K,
                                             int row0, int rows_wg, int grp, int lane) {
     mg_task t;
@@ -273,10 +299,11 @@ __device__ __forceinline__ mg_task mg_task8(unsigned (&pf)[96], const wa_f16 * W
     t.valid = ri < rows_wg && t.row < N;
     t.wrow = (gch) W + (size_t) (t.valid ? t.row : 0) * K + 4 * (lane & 7);
     t.bias = 0.0f; t.scale = 1.0f;
-    mg_pf8(pf, t.wrow, t.valid, K >> 5, 0);
+    mg_pf8<NS>(pf, t.wrow, t.valid, K >> 5, 0);
     if (t.valid && (lane & 7) == 0) { if (bias) t.bias = ((gcf) bias)[t.row]; if (scale) t.scale = ((gcf) scale)[t.row]; }
     return t;
 }
+template <int NS = 0>
 __device__ __forceinline__ mg_task mg_task16(unsigned (&pf)[96], const wa_f16 * W, const float * bias, int N, int K, int row0, int rows_wg,
                                              int grp, int lane) {
     mg_task t;
@@ -285,7 +312,7 @@ __device__ __forceinline__ mg_task mg_task16(unsigned (&pf)[96], const wa_f16 * 
     t.valid = ri < rows_wg && t.row < N;
     t.wrow = (gch) W + (size_t) (t.valid ? t.row : 0) * K + 2 * (lane & 15);
     t.bias = 0.0f; t.scale = 1.0f;
-    mg_pf16(pf, t.wrow, t.valid, K >> 5, 0);
+    mg_pf16<NS>(pf, t.wrow, t.valid, K >> 5, 0);
     if (t.valid && (lane & 15) == 0 && bias) t.bias = ((gcf) bias)[t.row];
     return t;
 }
@@ -305,7 +332,11 @@ __device__ __forceinline__ unsigned mg_pub_h2(gu64 * edge, unsigned seq, bool va
 // prediction only (fast exp, any order): the host re-derives every token from the logits with the reference's rules.
 // -------------------------------------------------------------------------------------------------
 #define MG_ATT_SMEM(maxkv) (8 * 8 + (maxkv) * 4 + ((maxkv) / 8) * 4 + 32 * 64 * 4 + 8 * 4 + 16 + (maxkv) * 2 + 64 * 2 + 64)      // LDS of the attention scratch (mg_att_carve)
-#define MG_PICK_OFF ((((size_t) WA_MEGA_MAX_KV * 64 * 2 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_KV)) + 255) & ~(size_t) 255)   // behind every role's LDS
+// LDS of a GEMV workgroup: xf [d] f32 | xin [4d] f16 | LayerNorm partial sums | the F16 GELU table (vec.h:571-585; 128 KB: the
+// FC1 epilogue's look-up is on the critical path of every layer, an L2 round trip there cost ~1 us)
+#define MG_LNRED_OFF ((size_t) WA_MEGA_MAX_D * 4 + (size_t) 4 * WA_MEGA_MAX_D * 2)
+#define MG_GELU_OFF  (MG_LNRED_OFF + 256)
+#define MG_PICK_OFF  (MG_GELU_OFF + 131072)        // behind every role's LDS (the GEMV role's is the largest)
 #define MG_PICK_BYTES 512
 struct mg_best { float v; int i; };
 __device__ __forceinline__ void mg_best_merge(mg_best & a, float v, int i) { if (v > a.v || (v == a.v && i < a.i)) { a.v = v; a.i = i; } }
@@ -355,22 +386,23 @@ __device__ __forceinline__ void mg_pick(mg_kargs A, int lane, int * pk) {
 // -------------------------------------------------------------------------------------------------
 // final LayerNorm + logits = token_embedding . x (whisper.cpp:2820-2835): every workgroup, every wave
 // -------------------------------------------------------------------------------------------------
+template <int NS = 0>
 __device__ __forceinline__ void mg_prefetch_logits(mg_kargs A, unsigned (&pf)[96], bool & have_pf, int lane, int wave) {
     const int g = (int) blockIdx.x + (int) gridDim.x * wave;
     const int row = g * 8 + (lane >> 3);
     const bool valid = row < A->n_vocab;
-    mg_pf8(pf, (gch) A->te + (size_t) (valid ? row : 0) * A->d + 4 * (lane & 7), valid, A->d >> 5, 0);
+    mg_pf8<NS>(pf, (gch) A->te + (size_t) (valid ? row : 0) * A->d + 4 * (lane & 7), valid, A->d >> 5, 0);
     have_pf = true;
 }
-template <int NPL>
-__device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char * smem, unsigned (&pf)[96], bool have_pf, const float (&gw)[NPL],
-                                         const float (&gb)[NPL], int lane, int wave) {
+template <int NP3, int NS>
+__device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char * smem, unsigned (&pf)[96], bool have_pf, const float (&gw)[NP3],
+                                         const float (&gb)[NP3], int lane, int wave) {
     float  * xf  = (float *) smem;
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);
+    double * lnred = (double *) (smem + MG_LNRED_OFF);
     const int d = A->d, nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab;
-    if (wave == 0) mg_gather_ln<NPL>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, lane, xf, xin, 3000u, blockIdx.x == 0 ? (A->n_layer * 8) * 8 : -1,
-                                     ((const int *) (smem + MG_PICK_OFF))[0]);
-    mg_barrier();
+    mg_ln3<NP3>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1), lane, xf, xin, lnred, 3000u,
+                blockIdx.x == 0 && wave == 0 ? (A->n_layer * 8) * 8 : -1, ((const int *) (smem + MG_PICK_OFF))[0]);
     const int NG = (n_vocab + 7) >> 3;
     GAS float * logits = (GAS float *) A->logits;
     // sampling state after this launch's token -> which logits the next pick may choose (whisper.cpp:6264-6302)
@@ -390,7 +422,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
         const bool valid = row < n_vocab;
         const unsigned mw = valid && (lane & 7) == 0 ? smask[row >> 5] : 0xffffffffu;
         const gch wrow = (gch) A->te + (size_t) (valid ? row : 0) * d + 4 * (lane & 7);
-        const float r = mg_dot8(pf, wrow, valid, d >> 5, xin, lane & 7, j == 0 && have_pf);
+        const float r = mg_dot8<NS>(pf, wrow, valid, d >> 5, xin, lane & 7, j == 0 && have_pf);
         if (valid && (lane & 7) == 0) {
             logits[row] = r;
             if (!((mw >> (row & 31)) & 1u)) {
@@ -434,7 +466,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
 // wave 3 the two out-projections, wave 4 the cross query, wave 5 FC2; waves 6,7 help gather the 4d-wide FC2 input.
 // Every wave loads the weights of its NEXT task right after finishing the current one.
 // -------------------------------------------------------------------------------------------------
-template <int NPL>
+template <int NP3, int NS>
 __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
@@ -458,29 +490,42 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     const int hf_seg = (((2 * d + 2) / 3 + 63) >> 6) << 6;      // FC2-input granules swept by each of the waves 0, 6, 7
     const int kv_head = A->kv_head;
 
-    float gw[NPL], gb[NPL];          // wave 0: gamma / beta of its next LayerNorm
+    double * lnred = (double *) (smem + MG_LNRED_OFF);
+    wa_f16 * gelu_l = (wa_f16 *) (smem + MG_GELU_OFF);
+    const int q = wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1);      // LayerNorm / gather slot of this wave
+    float gw[NP3], gb[NP3];          // gather waves: gamma / beta of their part of the next LayerNorm
     int * pk = (int *) (smem + MG_PICK_OFF);
-    if (wave == 0) { mg_ln_params<NPL>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, lane); mg_pick(A, lane, pk); }
+    mg_ln_params<NP3>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, q, lane);
+    if (wave == 0) mg_pick(A, lane, pk);
     mg_task t; t.valid = false; t.row = 0; t.wrow = nullptr; t.bias = 0.f; t.scale = 1.f;
-    if (wave == 1 || wave == 2) t = mg_task8(pf, Ly[0].qkv_w, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
-    else if (wave == 3)         t = mg_task8(pf, Ly[0].out_w, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
-    else if (wave == 4)         t = mg_task8(pf, Ly[0].cq_w, Ly[0].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
-    else if (wave == 5)         t = mg_task16(pf, Ly[0].fc2_w, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
-    else if (wave >= 6)         mg_prefetch_logits(A, pf, have_pf, lane, wave);      // held until the final phase
+    if (wave == 1 || wave == 2) t = mg_task8<NS>(pf, Ly[0].qkv_w, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+    else if (wave == 3)         t = mg_task8<NS>(pf, Ly[0].out_w, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+    else if (wave == 4)         t = mg_task8<NS>(pf, Ly[0].cq_w, Ly[0].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+    else if (wave == 5)         t = mg_task16<4 * NS>(pf, Ly[0].fc2_w, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
+    else if (wave >= 6)         mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);      // held until the final phase
+    mg_barrier();                   // the picked token is in LDS for the three embedding waves
+    if (wave >= 3 && wave <= 5) {   // GELU table -> LDS (needed first by FC1 of layer 0, several barriers from here)
+        const int t0 = (int) threadIdx.x - 192;
+        const GAS u32x4 * src = (const GAS u32x4 *) A->gelu;
+        for (int j0 = 0; j0 < 43; j0 += 8) {
+            u32x4 tv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int idx = t0 + 192 * (j0 + j); if (idx < 8192) tv[j] = src[idx]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int idx = t0 + 192 * (j0 + j); if (idx < 8192) *(u32x4 *) (gelu_l + (size_t) idx * 8) = tv[j]; }
+        }
+    }
 
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         // ---------------- P1: LayerNorm + q|k|v ----------------
-        if (wave == 0) {
-            mg_gather_ln<NPL>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, lane, xf, xin, 100u + l, wg == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
-            mg_ln_params<NPL>(gw, gb, Y.ln2_w, Y.ln2_b, d, lane);
-        }
-        mg_barrier();
+        mg_ln3<NP3>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, q, lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
+        mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, q, lane);
         if (wave == 1 || wave == 2) {
             gu64 * eq = mg_edge(A, l, E_QKV);
             for (int grp = wave - 1; grp < g_qkv; grp += 2) {
-                if (grp >= 2) t = mg_task8(pf, Y.qkv_w, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane);
-                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 2) t = mg_task8<NS>(pf, Y.qkv_w, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane);
+                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 v = v * t.scale;
                 const unsigned pk = mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
@@ -491,7 +536,7 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
                 }
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 0) * 8 + 3, mg_now());
-            t = mg_task8(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+            t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
         }
         // ---------------- P3: self-attention out-projection + residual ----------------
         if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO), 0, d >> 1, lane, (unsigned *) xin, 200u + l, A, wg == 0 ? (l * 8 + 1) * 8 : -1);
@@ -499,30 +544,27 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
         if (wave == 3) {
             gu64 * ex = mg_edge(A, l, E_X1);
             for (int grp = 0; grp < g_d8; ++grp) {
-                if (grp >= 1) t = mg_task8(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane);
-                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 1) t = mg_task8<NS>(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane);
+                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && lane == 0, (l * 8 + 1) * 8 + 3, mg_now());
-            t = mg_task8(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+            t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
-        if (wave == 0) {
-            mg_gather_ln<NPL>(A, c, mg_edge(A, l, E_X1), gw, gb, lane, xf, xin, 300u + l, wg == 0 ? (l * 8 + 2) * 8 : -1);
-            mg_ln_params<NPL>(gw, gb, Y.ln3_w, Y.ln3_b, d, lane);
-        }
-        mg_barrier();
+        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X1), gw, gb, q, lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
+        mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, q, lane);
         if (wave == 4) {
             gu64 * eq = mg_edge(A, l, E_QC);
             for (int grp = 0; grp < g_d8; ++grp) {
-                if (grp >= 1) t = mg_task8(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane);
-                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 1) t = mg_task8<NS>(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane);
+                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
             mg_trace(A, wg == 0 && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P6: cross-attention out-projection + residual ----------------
         if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO2), 0, d >> 1, lane, (unsigned *) xin, 400u + l, A, wg == 0 ? (l * 8 + 3) * 8 : -1);
@@ -530,34 +572,30 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
         if (wave == 3) {
             gu64 * ex = mg_edge(A, l, E_X2);
             for (int grp = 0; grp < g_d8; ++grp) {
-                if (grp >= 1) t = mg_task8(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane);
-                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 1) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane);
+                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
-        if (wave == 0) {
-            mg_gather_ln<NPL>(A, c, mg_edge(A, l, E_X2), gw, gb, lane, xf, xin, 500u + l, wg == 0 ? (l * 8 + 4) * 8 : -1);
-            if (l + 1 < L) mg_ln_params<NPL>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, lane);
-            else           mg_ln_params<NPL>(gw, gb, A->lnf_w, A->lnf_b, d, lane);
-        }
-        mg_barrier();
+        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X2), gw, gb, q, lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
+        if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, q, lane);
+        else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, q, lane);
         if (wave == 1 || wave == 2) {
             gu64 * eh = mg_edge(A, l, E_HF);
-            const gch gelu = (gch) A->gelu;
             for (int grp = wave - 1; grp < g_ff; grp += 2) {
-                if (grp >= 2) t = mg_task8(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane);
-                float v = mg_dot8(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 2) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane);
+                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
-                float gl = v;                                      // wa_gelu (vec.h:571-585) through the global F16 table
-                if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu[t.valid ? f2h(v) : 0]);
+                float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
+                if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
                 mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task8(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
         }
         // ---------------- P8: FC2 + residual ----------------
         if (wave == 0 || wave >= 6) {
@@ -569,17 +607,17 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
         if (wave == 5) {
             gu64 * ex = mg_edge(A, l, E_X3);
             for (int grp = 0; grp < g_d16; ++grp) {
-                if (grp >= 1) t = mg_task16(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, grp, lane);
-                float v = mg_dot16(pf, t.wrow, t.valid, d4 >> 5, xin, lane & 15, true);
+                if (grp >= 1) t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, grp, lane);
+                float v = mg_dot16<4 * NS>(pf, t.wrow, t.valid, d4 >> 5, xin, lane & 15, true);
                 v = v + t.bias;
                 if (t.valid && (lane & 15) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && lane == 0, (l * 8 + 5) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task16(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
+            if (l + 1 < L) t = mg_task16<4 * NS>(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
         }
     }
-    if (wave >= 1 && wave <= 5) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    mg_final<NPL>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
+    if (wave >= 1 && wave <= 5) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+    mg_final<NP3, NS>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -766,10 +804,10 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
     }
     unsigned pf[96];
     bool have_pf = false;
-    float gw[MG_NPL], gb[MG_NPL];
+    float gw[MG_NP3], gb[MG_NP3];
     if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    else mg_ln_params<MG_NPL>(gw, gb, A->lnf_w, A->lnf_b, A->d, lane);
-    mg_final<MG_NPL>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
+    mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1), lane);
+    mg_final<MG_NP3, 0>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -945,17 +983,17 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
     }
     unsigned pf[96];
     bool have_pf = false;
-    float gw[MG_NPL], gb[MG_NPL];
+    float gw[MG_NP3], gb[MG_NP3];
     if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    else mg_ln_params<MG_NPL>(gw, gb, A->lnf_w, A->lnf_b, A->d, lane);
-    mg_final<MG_NPL>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
+    mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1), lane);
+    mg_final<MG_NP3, 0>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A) {
     const int nG = (int) gridDim.x - 5 * A.n_head;       // H self-attention + 4 H cross-attention workgroups
     const int wg = blockIdx.x;
     const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();     // = &A (the struct is the only argument)
-    if (wg < nG) { if (A.d <= 768) mg_role_gemv<12>(Ap); else mg_role_gemv<MG_NPL>(Ap); }
+    if (wg < nG) { if (A.d == 768) mg_role_gemv<4, 24>(Ap); else if (A.d < 768) mg_role_gemv<4, 0>(Ap); else mg_role_gemv<MG_NP3, 0>(Ap); }
     else if (wg < nG + A.n_head) mg_role_self(Ap);
     else                         mg_role_cross(Ap);
 }
@@ -963,10 +1001,10 @@ __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A
 size_t wa_mega_lds_bytes() {
     const size_t s_self  = (size_t) WA_MEGA_MAX_KV * 64 * 2 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_KV);
     const size_t s_cross = 8192 + 4096 + 1536 + 768 + 64 + 128 + 64 + 32 + 16;
-    const size_t s_gemv  = (size_t) WA_MEGA_MAX_D * 4 + (size_t) 4 * WA_MEGA_MAX_D * 2;
+    const size_t s_gemv  = MG_PICK_OFF;
     size_t m = s_self > s_cross ? s_self : s_cross;
     m = m > s_gemv ? m : s_gemv;
-    if (((m + 255) & ~(size_t) 255) != MG_PICK_OFF) abort();      // the pick area sits right behind the largest role
+    if (m > MG_PICK_OFF || (MG_PICK_OFF & 255) != 0) abort();      // the pick area sits behind the largest role
     return MG_PICK_OFF + MG_PICK_BYTES;
 }
 
