@@ -487,7 +487,6 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     // drained vmcnt in front of the barrier: measured 3 us per LayerNorm phase)
     const __attribute__((address_space(4))) wa_mega_layer * Ly = (const __attribute__((address_space(4))) wa_mega_layer *) A->layers;
     const unsigned seq = c.seq;
-    const int hf_seg = (((2 * d + 2) / 3 + 63) >> 6) << 6;      // FC2-input granules swept by each of the waves 0, 6, 7
     const int kv_head = A->kv_head;
 
     double * lnred = (double *) (smem + MG_LNRED_OFF);
@@ -539,7 +538,10 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
         }
         // ---------------- P3: self-attention out-projection + residual ----------------
-        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO), 0, d >> 1, lane, (unsigned *) xin, 200u + l, A, wg == 0 ? (l * 8 + 1) * 8 : -1);
+        if (q >= 0) {
+            const int sg = (((d >> 1) + 2) / 3 + 63) & ~63, j0 = q * sg, j1 = min(d >> 1, j0 + sg);
+            mg_gather_h2<((WA_MEGA_MAX_D / 2 + 2) / 3 + 63) / 64>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
+        }
         mg_barrier();
         if (wave == 3) {
             gu64 * ex = mg_edge(A, l, E_X1);
@@ -567,7 +569,10 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P6: cross-attention out-projection + residual ----------------
-        if (wave == 0) mg_gather_h2<(WA_MEGA_MAX_D / 2 + 63) / 64>(c, mg_edge(A, l, E_AO2), 0, d >> 1, lane, (unsigned *) xin, 400u + l, A, wg == 0 ? (l * 8 + 3) * 8 : -1);
+        if (q >= 0) {
+            const int sg = (((d >> 1) + 2) / 3 + 63) & ~63, j0 = q * sg, j1 = min(d >> 1, j0 + sg);
+            mg_gather_h2<((WA_MEGA_MAX_D / 2 + 2) / 3 + 63) / 64>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
+        }
         mg_barrier();
         if (wave == 3) {
             gu64 * ex = mg_edge(A, l, E_X2);
@@ -598,10 +603,10 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
         }
         // ---------------- P8: FC2 + residual ----------------
-        if (wave == 0 || wave >= 6) {
-            const int gi = wave == 0 ? 0 : wave - 5;
-            const int i0 = gi * hf_seg, i1 = min(2 * d, i0 + hf_seg);
-            mg_gather_h2<(((2 * WA_MEGA_MAX_D + 2) / 3 + 63) / 64)>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
+        if (wave == 0 || wave == 3 || wave == 4 || wave >= 6) {     // the widest hand-off (2d granules): five waves poll a fifth each
+            const int gi = wave == 0 ? 0 : (wave >= 6 ? wave - 3 : wave - 2);       // 0, 1 (w3), 2 (w4), 3 (w6), 4 (w7)
+            const int sg = ((2 * d + 4) / 5 + 63) & ~63, i0 = gi * sg, i1 = min(2 * d, i0 + sg);
+            mg_gather_h2<((2 * WA_MEGA_MAX_D + 4) / 5 + 63) / 64>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
         mg_barrier();
         if (wave == 5) {
@@ -912,23 +917,25 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
         mg_barrier();
         mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 4, mg_now());
         const float mx = bc[0];
-        // ---- exp, group sums, F64 partial sum: thread = one own group of 8 cells (ops.cpp:4792-4818, vec.cpp:257-308) ----
-        double ps = 0.0;
-        if (tid < MG_CSTEPS) {
-            const int g = 4 * tid + w;                      // global group index of local step tid
-            float e[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int cc = 8 * g + r;
-                e[r] = cc < n8 ? wa_expf(sc[8 * tid + r] - mx) : (cc < T ? wa_expf_libm(sc[8 * tid + r] - mx) : 0.0f);
+        // ---- exp, group sums (8-lane tree = ops.cpp's), F64 partial sum: thread = one own cell (ops.cpp:4792-4818, vec.cpp:257-308) ----
+        {
+            double ps = 0.0;
+            if (tid < 8 * MG_CSTEPS) {
+                const int g = 4 * (tid >> 3) + w, cc = 8 * g + (tid & 7);          // global group / cell of local index tid
+                const float e = cc < n8 ? wa_expf(sc[tid] - mx) : (cc < T ? wa_expf_libm(sc[tid] - mx) : 0.0f);
+                sc[tid] = e;
+                float t = e + dpp_f32<0x104>(e);        // lanes r = 0..3 of the group: e[r] + e[r+4]
+                t = t + dpp_f32<0x102>(t);              // r = 0: (e0+e4)+(e2+e6)   r = 1: (e1+e5)+(e3+e7)
+                t = t + dpp_f32<0x101>(t);              // r = 0: the group sum, ops.cpp's tree
+                if (g < ng) ps = (tid & 7) == 0 ? (double) t : 0.0;
+                else ps = (double) e;                   // the n % 8 tail cells (any order: the total is certified below)
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) sc[8 * tid + r] = e[r];
-            if (g < ng) ps = (double) (((e[0] + e[4]) + (e[2] + e[6])) + ((e[1] + e[5]) + (e[3] + e[7])));
-            else { for (int r = 0; r < 8; ++r) if (8 * g + r < T) ps += (double) e[r]; }     // the n % 8 tail cells, index order
-        }
-        if (wave == 0) {        // (2) partial sums -> total, certified
             ps = wave_sum_d(ps);
+            if (lane == 0) redd[wave] = ps;
+        }
+        mg_barrier();
+        if (wave == 0) {        // (2) partial sums -> total, certified
+            const double ps = ((redd[0] + redd[1]) + (redd[2] + redd[3])) + ((redd[4] + redd[5]) + (redd[6] + redd[7]));
             const u64 pb = (u64) __double_as_longlong(ps);
             if (lane == 0) { gr_store(X + MG_CGR_SUM + 2 * w, seq, (unsigned) pb); gr_store(X + MG_CGR_SUM + 2 * w + 1, seq, (unsigned) (pb >> 32)); }
             unsigned v[1];
@@ -951,7 +958,7 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
             const int cc = 32 * (tid >> 3) + 8 * w + (tid & 7);
             if (cc < T) {
                 const wa_f16 ph = f2h(sc[tid] * inv);
-                p16[tid] = ph;
+                p16[(tid & 7) * MG_CSTEPS + (tid >> 3)] = ph;         // by chain: the P V wave reads its 48 probabilities as 6 x 16 bytes
                 if (cc >= np) { if (w == 0) pleft[cc - np] = ph; else gr_store(X + MG_CGR_PART + (w - 1) * 576 + 512 + (tid & 7), seq, (unsigned) ph); }
             }
         }
@@ -959,8 +966,11 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
         // ---- P V: wave = own chain (cells 32 s + 8 w + wave), lane = d_head index ----
         {
             float acc = 0.0f;
+            half8 pw[MG_CSTEPS / 8];
 #pragma unroll
-            for (int s = 0; s < MG_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(vv[s]), h2f(p16[8 * s + wave]), acc);
+            for (int k = 0; k < MG_CSTEPS / 8; ++k) pw[k] = *(const half8 *) (p16 + wave * MG_CSTEPS + 8 * k);
+#pragma unroll
+            for (int s = 0; s < MG_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(vv[s]), (float) pw[s >> 3][s & 7], acc);
             if (w == 0) part[wave * 64 + lane] = acc;
             else gr_store(X + MG_CGR_PART + (w - 1) * 576 + wave * 64 + lane, seq, __float_as_uint(acc));
         }
