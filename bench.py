@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--model", default="small", choices=list(wsynth.SHAPES))
     ap.add_argument("--chunks-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the 4-concurrent-chunks extra (threads + graph capture upset rocprofv3)")
     ap.add_argument("--flash-attn", type=int, default=1, help="1 = MFMA fast path (default), 0 = reference-order path")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
@@ -201,18 +202,26 @@ def main():
         n_past = 64
         rc = lib.whisper_amd_decode_step_probe(ctx.ptr, st.ptr, n_past, 200, C.byref(ms))
         dbytes = decode_bytes(shape, n_past)
+        lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
         if rc == 0 and ms.value > 0:
             gbs = dbytes / (ms.value * 1e-3) / 1e9
-            lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
+            # HBM bytes per launch from the PMC counters (collected off-line with tools/profile_gpu.sh, one counter per pass, summary
+            # committed under profiles/): 2 x FETCH_SIZE (gfx950 tallies 128-byte reads at 64 bytes) + WRITE_SIZE, in KiB
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_decode_step_pmc.json")
+            if args.model == "small" and os.path.exists(pmc) and lib.whisper_amd_mega_enabled(st.ptr):
+                pj = json.load(open(pmc))
+                traffic = int((2 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024)
+                traffic_src = "profiles/r01_decode_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2)"
             kname = ("k_decode_mega: the whole single-token decoder pass as ONE persistent launch (256 workgroups, granule hand-offs), n_past=64"
                      if lib.whisper_amd_mega_enabled(st.ptr) else
                      "decode step = hipGraph of 122 launches (k_gemv_exact weight streaming + k_attn_exact), 1 token, n_past=64")
             out["roofline"] = {"bound": "hbm", "kernel": kname,
                                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                               "traffic": None, "bytes_per_step": dbytes, "ms_per_step_device": round(ms.value, 4),
+                               "traffic": traffic, "traffic_source": traffic_src, "bytes_per_step": dbytes, "ms_per_step_device": round(ms.value, 4),
                                "ms_per_token_wall_in_full": round(dec_ms_wall, 4)}
         # ---- throughput mode on the same GPU: 4 independent chunks transcribed concurrently (one stream + host thread each)
-        if world == 1:
+        if world == 1 and not args.no_concurrent:
             try:
                 tst = [ctx.create_state() for _ in range(4)]
                 tp = [hip.to_device(wsynth.synth_audio(480000, 100 + i)) for i in range(4)]
