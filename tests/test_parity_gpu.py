@@ -295,3 +295,32 @@ def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok
         tok = int(np.argmax(a[:50000]))
     assert amd_lib.whisper_amd_mega_enabled(meg.ptr) == 1, "the one-launch step gave up (hand-off time-out) and fell back"
     ref.free(); meg.free(); ctx.free()
+
+
+def test_host_overlap_never_changes_results(wrs, amd_lib, monkeypatch):
+    """Greedy decoding with the device predicting the next token (host overlap) must give the segments of the plain loop -
+    also when the prediction is wrong on purpose (every third token id hidden from the device), which exercises the
+    discard-and-redo path; and the predictions must actually have been used / refused."""
+    amd_lib.whisper_amd_overlap_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    amd_lib.whisper_amd_reset_timings.argtypes = [C.c_void_p]
+    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    pcm = wsynth.synth_audio(480000, 2)
+    fp = wrs.FullParams(amd_lib, best_of=1, temperature_inc=0.0)
+    out = {}
+    for mode, env in (("plain", {"WHISPER_AMD_NO_OVERLAP": "1"}), ("overlap", {}), ("sabotage", {"WHISPER_AMD_OVERLAP_SABOTAGE": "1"})):
+        for k in ("WHISPER_AMD_NO_OVERLAP", "WHISPER_AMD_OVERLAP_SABOTAGE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        st = ctx.create_state()
+        amd_lib.whisper_amd_reset_timings(st.ptr)
+        st.full(fp, pcm)
+        ov = (C.c_int * 2)(); amd_lib.whisper_amd_overlap_stats(st.ptr, ov)
+        out[mode] = (_segs(st), ov[0], ov[1])
+        st.free()
+    assert out["plain"][1] == 0 and out["plain"][2] == 0
+    assert out["overlap"][1] > 0, "the overlap path did not run"
+    assert out["sabotage"][2] > 0, "no wrong prediction was produced by the sabotaged mask"
+    _same(out["plain"][0], out["overlap"][0]); _same(out["plain"][0], out["sabotage"][0])
+    assert sum(len(s["ids"]) for s in out["plain"][0]) > 0
+    ctx.free()

@@ -238,7 +238,15 @@ bool wa_spec_begin(whisper_context & ctx, whisper_state & st, const std::vector<
         if (!WA_HIP_OK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking))) { st.copy_stream = nullptr; return false; }
     }
     g_mega_mutex.lock();       // exclusive use of the device's one-launch slot until wa_spec_end
-    (void) hipMemcpyAsync(st.d_mega_smask, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st.stream);
+    std::vector<uint32_t> sab;
+    if (const char * e = getenv("WHISPER_AMD_OVERLAP_SABOTAGE")) {      // tests: make the device's prediction wrong on purpose (every
+        if (e[0] == '1') {                                              // 3rd token id is hidden from it) - results must not change
+            sab = bits;
+            for (size_t i = 0; i < sab.size(); ++i) sab[i] |= 0x49249249u << (i % 3);
+        }
+    }
+    const std::vector<uint32_t> & up = sab.empty() ? bits : sab;
+    (void) hipMemcpyAsync(st.d_mega_smask, up.data(), up.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st.stream);
     return WA_HIP_OK(hipStreamSynchronize(st.stream));
 }
 
