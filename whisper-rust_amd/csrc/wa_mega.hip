@@ -415,14 +415,17 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
     const GAS unsigned * smask = (const GAS unsigned *) A->smask;
     mg_best bt = { -INFINITY, 0x7fffffff }, bs = { -INFINITY, 0x7fffffff };
     float s_ts = 0.0f;
-    for (int j = 0;; ++j) {
-        const int g = wg + nwg * (wave + MG_NW * j);
-        if (g >= NG) break;
-        const int row = g * 8 + (lane >> 3);
+    // row groups g(j) = wg + nwg (wave + 8 j) of this wave, two weight buffers: the loads of group j + 1 fly during group j
+    unsigned pf2[96];
+    const int ns = d >> 5;
+    auto grp  = [&](int j) { return wg + nwg * (wave + MG_NW * j); };
+    auto wrow = [&](int j) { const int row = grp(j) * 8 + (lane >> 3); return (gch) A->te + (size_t) (row < n_vocab ? row : 0) * d + 4 * (lane & 7); };
+    auto vld  = [&](int j) { return grp(j) * 8 + (lane >> 3) < n_vocab; };
+    auto one = [&](int j, unsigned (&buf)[96]) {
+        const int row = grp(j) * 8 + (lane >> 3);
         const bool valid = row < n_vocab;
         const unsigned mw = valid && (lane & 7) == 0 ? smask[row >> 5] : 0xffffffffu;
-        const gch wrow = (gch) A->te + (size_t) (valid ? row : 0) * d + 4 * (lane & 7);
-        const float r = mg_dot8<NS>(pf, wrow, valid, d >> 5, xin, lane & 7, j == 0 && have_pf);
+        const float r = mg_dot8<NS>(buf, wrow(j), valid, ns, xin, lane & 7, ns <= 48);
         if (valid && (lane & 7) == 0) {
             logits[row] = r;
             if (!((mw >> (row & 31)) & 1u)) {
@@ -434,6 +437,14 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
                 } else if (!(no_text && row < eot)) mg_best_merge(bt, r, row);
             }
         }
+    };
+    if (!have_pf && grp(0) < NG) mg_pf8<NS>(pf, wrow(0), vld(0), ns, 0);
+    for (int j = 0; grp(j) < NG; j += 2) {
+        if (grp(j + 1) < NG) mg_pf8<NS>(pf2, wrow(j + 1), vld(j + 1), ns, 0);
+        one(j, pf);
+        if (grp(j + 1) >= NG) break;
+        if (grp(j + 2) < NG) mg_pf8<NS>(pf, wrow(j + 2), vld(j + 2), ns, 0);
+        one(j + 1, pf2);
     }
     {   // this workgroup's record
         unsigned * rb = (unsigned *) (smem + MG_PICK_OFF + 64);
@@ -503,16 +514,10 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     else if (wave == 5)         t = mg_task16<4 * NS>(pf, Ly[0].fc2_w, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
     else if (wave >= 6)         mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);      // held until the final phase
     mg_barrier();                   // the picked token is in LDS for the three embedding waves
-    if (wave >= 3 && wave <= 5) {   // GELU table -> LDS (needed first by FC1 of layer 0, several barriers from here)
-        const int t0 = (int) threadIdx.x - 192;
+    if (wave >= 3 && wave <= 5) {   // GELU table -> LDS by LDS-DMA (no registers, nothing waits here); first needed by FC1 of layer 0
         const GAS u32x4 * src = (const GAS u32x4 *) A->gelu;
-        for (int j0 = 0; j0 < 43; j0 += 8) {
-            u32x4 tv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const int idx = t0 + 192 * (j0 + j); if (idx < 8192) tv[j] = src[idx]; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const int idx = t0 + 192 * (j0 + j); if (idx < 8192) *(u32x4 *) (gelu_l + (size_t) idx * 8) = tv[j]; }
-        }
+        for (int j = wave - 3; j < 128; j += 3)         // 128 wave-instructions of 64 x 16 bytes
+            __builtin_amdgcn_global_load_lds((const GAS void *) (src + j * 64 + lane), (__attribute__((address_space(3))) void *) (smem + MG_GELU_OFF + (size_t) j * 1024), 16, 0, 0);
     }
 
     for (int l = 0; l < L; ++l) {
@@ -586,6 +591,7 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
+        if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
         mg_ln3<NP3>(A, c, mg_edge(A, l, E_X2), gw, gb, q, lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
         if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, q, lane);
         else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, q, lane);
