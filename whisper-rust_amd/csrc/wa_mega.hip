@@ -793,7 +793,35 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
             }
         }
         mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 4, mg_now());
-        mg_softmax(M, n_kv, lmax, tid, lane, wave);
+        {   // soft_max (ops.cpp:4792-4818, vec.cpp:257-308) with one cell per thread (n_kv <= 512) and three barriers: maximum;
+            // exp + the 8-lane group tree + F64 partial sums; every thread certifies the total and scales its own cell
+            lmax = wave_max(lmax);
+            if (lane == 0) M.red[wave] = lmax;
+            mg_barrier();
+            float mx = M.red[0];
+#pragma unroll
+            for (int k = 1; k < MG_NW; ++k) mx = fmaxf(mx, M.red[k]);
+            const int n8 = n_kv & ~7, ng = n8 >> 3;
+            float e = 0.0f;
+            double ps = 0.0;
+            if (tid < n_kv) e = tid < n8 ? wa_expf(M.sc[tid] - mx) : wa_expf_libm(M.sc[tid] - mx);
+            {
+                float t = e + dpp_f32<0x104>(e);        // lanes r = 0..3 of a group of 8 cells: e[r] + e[r+4]
+                t = t + dpp_f32<0x102>(t);              // r = 0: (e0+e4)+(e2+e6)   r = 1: (e1+e5)+(e3+e7)
+                t = t + dpp_f32<0x101>(t);              // r = 0: the group sum in ops.cpp's order
+                if (tid < n8) ps = (tid & 7) == 0 ? (double) t : 0.0;
+                else if (tid < n_kv) ps = (double) e;   // the n % 8 tail cells
+            }
+            ps = wave_sum_d(ps);
+            if (lane == 0) M.redd[wave] = ps;
+            mg_barrier();
+            const double tot = ((M.redd[0] + M.redd[1]) + (M.redd[2] + M.redd[3])) + ((M.redd[4] + M.redd[5]) + (M.redd[6] + M.redd[7]));
+            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
+            const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
+            if (ilo != ihi && tid == 0 && !c.dead) __hip_atomic_store(c.status, (unsigned) WA_MEGA_REDO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < n_kv) M.p16[tid] = f2h(e * ilo);
+            mg_barrier();
+        }
         mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 5, mg_now());
         // ---- P V: chains r = cell mod 32 (4 per wave), lane = d_head index ----
         const int np = n_kv & ~31, nsteps = np >> 5;
