@@ -20,6 +20,10 @@ __device__ __forceinline__ float h2f(wa_f16 v) { union { wa_f16 u; h16 h; } c; c
 // different soft-max probability every few thousand values).
 __device__ __forceinline__ wa_f16 f2h(float v) { asm("" : "+v"(v)); union { wa_f16 u; h16 h; } c; c.h = (h16) v; return c.u; }
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains the vector-memory counter (s_waitcnt vmcnt(0)), i.e. every
+// wave would wait at it for global loads it has only just issued as a prefetch.
+__device__ __forceinline__ void wa_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);

@@ -467,20 +467,31 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
 
-    auto load_k = [&](int kt) {
+    // K / V^T tiles go global -> registers -> LDS: the loads of tile kt + 1 are issued before tile kt is computed, so their HBM / L2
+    // round trip (1-2 us, once per tile and sweep: most of this kernel's time when it was exposed) hides behind the MFMAs
+    uint4 kreg[2], vreg[2];
+    auto fetch_k = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
             int key = kt * 64 + row; key = key < T ? key : T - 1;
-            *(uint4 *) (&Ks[row * ATT_LD + kc * 8]) = *(const uint4 *) (qk + (size_t) key * ldqk + d + h * 64 + kc * 8);
+            kreg[i] = *(const uint4 *) (qk + (size_t) key * ldqk + d + h * 64 + kc * 8);
         }
     };
-    auto load_v = [&](int kt) {
+    auto fetch_v = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i, row = c >> 3, kc = c & 7;   // row = dh, kc = key chunk
-            *(uint4 *) (&Vs[row * ATT_LD + kc * 8]) = *(const uint4 *) (vt + (size_t) (h * 64 + row) * ldvt + kt * 64 + kc * 8);
+            vreg[i] = *(const uint4 *) (vt + (size_t) (h * 64 + row) * ldvt + kt * 64 + kc * 8);
         }
+    };
+    auto store_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int c = tid + 256 * i; *(uint4 *) (&Ks[(c >> 3) * ATT_LD + (c & 7) * 8]) = kreg[i]; }
+    };
+    auto store_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int c = tid + 256 * i; *(uint4 *) (&Vs[(c >> 3) * ATT_LD + (c & 7) * 8]) = vreg[i]; }
     };
     auto scores = [&](int kt, f32x4 (&s)[4]) {
 #pragma unroll
@@ -498,10 +509,12 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
     };
 
     // ---- sweep 1: row max and sum of exp ----
+    fetch_k(0);
     for (int kt = 0; kt < n_tiles; ++kt) {
         __syncthreads();
-        load_k(kt);
-        __syncthreads();
+        store_k();
+        if (kt + 1 < n_tiles) fetch_k(kt + 1);
+        wa_barrier_lds();
         f32x4 s[4];
         scores(kt, s);
 #pragma unroll
@@ -526,11 +539,12 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
     f32x4 o_acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o_acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    fetch_k(0); fetch_v(0);
     for (int kt = 0; kt < n_tiles; ++kt) {
         __syncthreads();
-        load_k(kt);
-        load_v(kt);
-        __syncthreads();
+        store_k(); store_v();
+        if (kt + 1 < n_tiles) { fetch_k(kt + 1); fetch_v(kt + 1); }
+        wa_barrier_lds();
         f32x4 s[4];
         scores(kt, s);
 #pragma unroll
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
                 const float p = fast_expf(s[nt][r] - m_run[r]) * inv_l[r];
                 Ps[wave][(fg * 4 + r) * ATT_LD + nt * 16 + fr] = f2h(p);
             }
-        __syncthreads();
+        wa_barrier_lds();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const half8 a = *(const half8 *) (&Ps[wave][fr * ATT_LD + ks * 32 + fg * 8]);

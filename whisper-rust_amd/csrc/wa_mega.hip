@@ -37,7 +37,7 @@ __device__ __forceinline__ mg_kargs mg_uniform(mg_kargs p) {
 
 #define MG_THREADS 512
 #define MG_NW (MG_THREADS / 64)
-#define MG_NP3 7                  // LayerNorm elements per lane of one of the three gather waves: d <= 1344
+#define MG_NP3 4                  // LayerNorm elements per lane of one of the six gather waves: d <= 1536
 #define MG_SPIN_LIMIT 300000u     // polls (~0.5 us each) before a hand-off is declared dead
 
 enum { E_QKV = 0, E_AO, E_X1, E_QC, E_AO2, E_X2, E_HF, E_X3 };
@@ -90,13 +90,29 @@ __device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int la
 }
 
 // -------------------------------------------------------------------------------------------------
-// LayerNorm phases.  THREE waves (0, 6, 7 = slots q 0..2; every other wave passes q < 0 and only keeps the barriers) each
-// obtain a third of the F32 residual row - from granules, or from the embeddings for layer 0 -, keep it in LDS (xf) and
-// write their third of LayerNorm(row) as F16 into xin.  ops.cpp:3225-3242 semantics as k_layernorm_exact: F64 sums in an
+// LayerNorm phases.  SIX waves (slots q 0..5, mg_slot; the others pass q < 0 and only keep the barriers) each
+// obtain a sixth of the F32 residual row - from granules, or from the embeddings for layer 0 -, keep it in LDS (xf) and
+// write their part of LayerNorm(row) as F16 into xin.  ops.cpp:3225-3242 semantics as k_layernorm_exact: F64 sums in an
 // arbitrary order, accepted when certified order-independent, else redone in index order (by each slot, identically).
-// A single wave polling all d granules took ~2 us per pass and 1.6 us for the arithmetic; a third each is faster on both.
+// A single wave polling all d granules took ~2 us per pass and 1.6 us for the arithmetic; a sixth each is faster on both.
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mg_ln_seg(int d) { return ((d + 191) / 192) * 64; }
+// Gathering is shared by SIX waves: the six lowest-numbered waves not in `ex` (the waves that have only just issued a weight
+// prefetch - a poll behind it would wait for those loads first, vmcnt being in order).  Returns the wave's slot or -1.
+#define MG_NQ 6
+#define MG_EX_P1 0x20u      /* wave 5 has just prefetched the next FC2 rows */
+#define MG_EX_P4 0x08u      /* wave 3: next out-projection rows */
+#define MG_EX_P7 0x08u
+#define MG_EX_AO 0x06u      /* waves 1, 2: FC1 rows */
+#define MG_EX_AO2 0x10u     /* wave 4: next cross-query rows */
+#define MG_EX_HF 0x06u      /* waves 1, 2: next QKV rows */
+#define MG_EX_FINAL 0x20u   /* wave 5: first logits rows */
+__device__ __forceinline__ int mg_slot(int wave, unsigned ex) {
+    if ((ex >> wave) & 1u) return -1;
+    const int sl = __builtin_popcount(~ex & ((1u << wave) - 1u) & 0xffu);
+    return sl < MG_NQ ? sl : -1;
+}
+__device__ __forceinline__ int mg_seg(int n) { return ((n + MG_NQ - 1) / MG_NQ + 31) & ~31; }      // granules per slot
+__device__ __forceinline__ int mg_ln_seg(int d) { return mg_seg(d); }
 template <int NP3>
 __device__ __forceinline__ void mg_ln_params(float (&gw)[NP3], float (&gb)[NP3], const float * lw, const float * lb, int d, int q, int lane) {
     const int seg = mg_ln_seg(d), i0 = q * seg, i1 = min(d, i0 + seg);
@@ -131,13 +147,13 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
 #pragma unroll
         for (int k = 0; k < NP3; ++k) { const int i = i0 + lane + 64 * k; if (i < i1) xf[i] = xv[k]; s += (double) xv[k]; a += (double) fabsf(xv[k]); }
         s = wave_sum_d(s); a = wave_sum_d(a);
-        if (lane == 0) { lnred[q] = s; lnred[3 + q] = a; }
+        if (lane == 0) { lnred[q] = s; lnred[MG_NQ + q] = a; }
     }
     mg_barrier();
     float mean = 0.0f;
     if (q >= 0) {
-        double s = (lnred[0] + lnred[1]) + lnred[2];
-        const double a = (lnred[3] + lnred[4]) + lnred[5];
+        double s = ((lnred[0] + lnred[1]) + (lnred[2] + lnred[3])) + (lnred[4] + lnred[5]);
+        const double a = ((lnred[6] + lnred[7]) + (lnred[8] + lnred[9])) + (lnred[10] + lnred[11]);
         if (!wa_sum_certain(s, a, d, mean)) {
             if (lane == 0) s = wa_seq_sum_lds(xf, d, false, 0.0f);
             s = __shfl(s, 0, WAVE);
@@ -147,11 +163,11 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
 #pragma unroll
         for (int k = 0; k < NP3; ++k) if (i0 + lane + 64 * k < i1) { const float t = xv[k] - mean; s2 += (double) (t * t); }
         s2 = wave_sum_d(s2);
-        if (lane == 0) lnred[6 + q] = s2;
+        if (lane == 0) lnred[2 * MG_NQ + q] = s2;
     }
     mg_barrier();
     if (q >= 0) {
-        double s2 = (lnred[6] + lnred[7]) + lnred[8];
+        double s2 = ((lnred[12] + lnred[13]) + (lnred[14] + lnred[15])) + (lnred[16] + lnred[17]);
         float variance;
         if (!wa_sum_certain(s2, s2, d, variance)) {
             if (lane == 0) s2 = wa_seq_sum_lds(xf, d, true, mean);
@@ -401,7 +417,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);
     double * lnred = (double *) (smem + MG_LNRED_OFF);
     const int d = A->d, nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab;
-    mg_ln3<NP3>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1), lane, xf, xin, lnred, 3000u,
+    mg_ln3<NP3>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, mg_slot(wave, MG_EX_FINAL), lane, xf, xin, lnred, 3000u,
                 blockIdx.x == 0 && wave == 0 ? (A->n_layer * 8) * 8 : -1, ((const int *) (smem + MG_PICK_OFF))[0]);
     const int NG = (n_vocab + 7) >> 3;
     GAS float * logits = (GAS float *) A->logits;
@@ -502,10 +518,9 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
 
     double * lnred = (double *) (smem + MG_LNRED_OFF);
     wa_f16 * gelu_l = (wa_f16 *) (smem + MG_GELU_OFF);
-    const int q = wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1);      // LayerNorm / gather slot of this wave
     float gw[NP3], gb[NP3];          // gather waves: gamma / beta of their part of the next LayerNorm
     int * pk = (int *) (smem + MG_PICK_OFF);
-    mg_ln_params<NP3>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, q, lane);
+    mg_ln_params<NP3>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
     if (wave == 0) mg_pick(A, lane, pk);
     mg_task t; t.valid = false; t.row = 0; t.wrow = nullptr; t.bias = 0.f; t.scale = 1.f;
     if (wave == 1 || wave == 2) t = mg_task8<NS>(pf, Ly[0].qkv_w, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
@@ -523,8 +538,8 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         // ---------------- P1: LayerNorm + q|k|v ----------------
-        mg_ln3<NP3>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, q, lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
-        mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, q, lane);
+        mg_ln3<NP3>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
+        mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, mg_slot(wave, MG_EX_P4), lane);
         if (wave == 1 || wave == 2) {
             gu64 * eq = mg_edge(A, l, E_QKV);
             for (int grp = wave - 1; grp < g_qkv; grp += 2) {
@@ -543,9 +558,9 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
         }
         // ---------------- P3: self-attention out-projection + residual ----------------
-        if (q >= 0) {
-            const int sg = (((d >> 1) + 2) / 3 + 63) & ~63, j0 = q * sg, j1 = min(d >> 1, j0 + sg);
-            mg_gather_h2<((WA_MEGA_MAX_D / 2 + 2) / 3 + 63) / 64>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
+        {
+            const int qs = mg_slot(wave, MG_EX_AO), sg = mg_seg(d >> 1), j0 = qs * sg, j1 = min(d >> 1, j0 + sg);
+            if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
         }
         mg_barrier();
         if (wave == 3) {
@@ -560,8 +575,8 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
-        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X1), gw, gb, q, lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
-        mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, q, lane);
+        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
+        mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, mg_slot(wave, MG_EX_P7), lane);
         if (wave == 4) {
             gu64 * eq = mg_edge(A, l, E_QC);
             for (int grp = 0; grp < g_d8; ++grp) {
@@ -572,11 +587,12 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             }
             mg_trace(A, wg == 0 && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
         }
         // ---------------- P6: cross-attention out-projection + residual ----------------
-        if (q >= 0) {
-            const int sg = (((d >> 1) + 2) / 3 + 63) & ~63, j0 = q * sg, j1 = min(d >> 1, j0 + sg);
-            mg_gather_h2<((WA_MEGA_MAX_D / 2 + 2) / 3 + 63) / 64>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
+        {
+            const int qs = mg_slot(wave, MG_EX_AO2), sg = mg_seg(d >> 1), j0 = qs * sg, j1 = min(d >> 1, j0 + sg);
+            if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
         }
         mg_barrier();
         if (wave == 3) {
@@ -589,12 +605,13 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             }
             mg_trace(A, wg == 0 && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
         }
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
         if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
-        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X2), gw, gb, q, lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
-        if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, q, lane);
-        else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, q, lane);
+        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
+        if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
+        else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, mg_slot(wave, MG_EX_FINAL), lane);
         if (wave == 1 || wave == 2) {
             gu64 * eh = mg_edge(A, l, E_HF);
             for (int grp = wave - 1; grp < g_ff; grp += 2) {
@@ -607,12 +624,12 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
         }
         // ---------------- P8: FC2 + residual ----------------
-        if (wave == 0 || wave == 3 || wave == 4 || wave >= 6) {     // the widest hand-off (2d granules): five waves poll a fifth each
-            const int gi = wave == 0 ? 0 : (wave >= 6 ? wave - 3 : wave - 2);       // 0, 1 (w3), 2 (w4), 3 (w6), 4 (w7)
-            const int sg = ((2 * d + 4) / 5 + 63) & ~63, i0 = gi * sg, i1 = min(2 * d, i0 + sg);
-            mg_gather_h2<((2 * WA_MEGA_MAX_D + 4) / 5 + 63) / 64>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
+        {   // the widest hand-off (2d granules)
+            const int qs = mg_slot(wave, MG_EX_HF), sg = mg_seg(2 * d), i0 = qs * sg, i1 = min(2 * d, i0 + sg);
+            if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
         mg_barrier();
         if (wave == 5) {
@@ -625,9 +642,10 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
             }
             mg_trace(A, wg == 0 && lane == 0, (l * 8 + 5) * 8 + 3, mg_now());
             if (l + 1 < L) t = mg_task16<4 * NS>(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
+            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
         }
     }
-    if (wave >= 1 && wave <= 5) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+    if (L == 0 && wave >= 1 && wave <= 5) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
     mg_final<NP3, NS>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
@@ -845,7 +863,7 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
     bool have_pf = false;
     float gw[MG_NP3], gb[MG_NP3];
     if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1), lane);
+    mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, mg_slot(wave, MG_EX_FINAL), lane);
     mg_final<MG_NP3, 0>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
@@ -1029,7 +1047,7 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
     bool have_pf = false;
     float gw[MG_NP3], gb[MG_NP3];
     if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
-    mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, wave == 0 ? 0 : (wave >= 6 ? wave - 5 : -1), lane);
+    mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, mg_slot(wave, MG_EX_FINAL), lane);
     mg_final<MG_NP3, 0>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
@@ -1037,7 +1055,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A
     const int nG = (int) gridDim.x - 5 * A.n_head;       // H self-attention + 4 H cross-attention workgroups
     const int wg = blockIdx.x;
     const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();     // = &A (the struct is the only argument)
-    if (wg < nG) { if (A.d == 768) mg_role_gemv<4, 24>(Ap); else if (A.d < 768) mg_role_gemv<4, 0>(Ap); else mg_role_gemv<MG_NP3, 0>(Ap); }
+    if (wg < nG) { if (A.d == 768) mg_role_gemv<2, 24>(Ap); else if (A.d < 768) mg_role_gemv<2, 0>(Ap); else mg_role_gemv<MG_NP3, 0>(Ap); }
     else if (wg < nG + A.n_head) mg_role_self(Ap);
     else                         mg_role_cross(Ap);
 }
