@@ -96,6 +96,10 @@ def main():
         dist = dist_mod
         n_dev = torch.cuda.device_count()
         local_dev = local_rank % max(1, n_dev)          # rehearsal: several ranks may share one card
+        if world > max(1, n_dev):
+            # ranks sharing a card: the one-launch decode step wants every CU for itself (its workgroups wait for each other, two of
+            # them interleaved could starve) - the rehearsal runs the launch sequence; one rank per GPU (the real run) is unaffected
+            os.environ["WHISPER_AMD_NO_MEGA"] = "1"
         torch.cuda.set_device(local_dev)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
