@@ -324,3 +324,26 @@ def test_host_overlap_never_changes_results(wrs, amd_lib, monkeypatch):
     _same(out["plain"][0], out["overlap"][0]); _same(out["plain"][0], out["sabotage"][0])
     assert sum(len(s["ids"]) for s in out["plain"][0]) > 0
     ctx.free()
+
+
+def test_heuristic_token_timestamps_and_segment_wrap_match_reference(wrs, amd_lib):
+    """params.token_timestamps (+ max_len / split_on_word): per-token t0 / t1 / vlen from the |PCM| energy heuristic and the
+    wrapped segments, identical to the reference engine's (goldens: tools/gen_golden_tts.py), with host and device PCM."""
+    import ctypes as C2
+    sys_path_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    if sys_path_tools not in sys.path:
+        sys.path.insert(0, sys_path_tools)
+    import gen_golden_tts as g
+    gold = json.load(open(os.path.join(GOLDEN, "s128_token_ts.json")))
+    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    for tag, kw in g.TTS_CASES.items():
+        for aseed in (0, 1):
+            st = ctx.create_state()
+            st.full(wrs.FullParams(amd_lib, 0, **kw), wsynth.synth_audio(480000, aseed))
+            got, want = g.segs(st), gold["%s_seed%d" % (tag, aseed)]
+            assert len(got) == len(want), (tag, aseed, len(got), len(want))
+            for a, b in zip(got, want):
+                assert a == b, (tag, aseed, a, b)
+            st.free()
+    ctx.free()

@@ -88,6 +88,177 @@ void compute_probs(const float * logits, int n, const float * logprobs, float * 
     for (int i = 0; i < n; ++i) probs[i] = logits[i] == -INFINITY ? 0.0f : expf(logprobs[i]);
 }
 
+// -------------------------------------------------------------------------------------------------
+// heuristic token-level timestamps and segment wrapping (params.token_timestamps / max_len / split_on_word).
+// Host-side post-processing of a finished segment; behavioural contract whisper.cpp:8326-8616 and 6047-6100:
+//   1. tokens whose timestamp guess is trusted (pt > thold_pt, ptsum > thold_ptsum, increasing) anchor the time line;
+//   2. the stretches between anchors are split in proportion to a "voice length" of each token's text;
+//   3. every text token's ends then slide to where the |PCM| energy (average over 65 samples) crosses half the local mean.
+// All arithmetic types and orders follow the reference (int64 / float / double as there), so results are identical.
+// -------------------------------------------------------------------------------------------------
+float voice_length(const char * text) {                      // whisper.cpp:8335-8357
+    float res = 0.0f;
+    for (const char * c = text; *c; ++c) {
+        if (*c == ' ') res += 0.01f;
+        else if (*c == ',') res += 2.00f;
+        else if (*c == '.' || *c == '!' || *c == '?') res += 3.00f;
+        else if (*c >= '0' && *c <= '9') res += 3.00f;
+        else res += 1.00f;
+    }
+    return res;
+}
+
+std::vector<float> signal_energy(const float * signal, int n, int hw) {      // whisper.cpp:8360-8376: mean |x| over [i - hw, i + hw]
+    std::vector<float> out(n);
+    for (int i = 0; i < n; ++i) {
+        float sum = 0;
+        const int j0 = std::max(-hw, -i), j1 = std::min(hw, n - 1 - i);
+        for (int j = j0; j <= j1; ++j) sum += fabsf(signal[i + j]);
+        out[i] = sum / (2 * hw + 1);
+    }
+    return out;
+}
+
+int ts_to_sample(int64_t t, int64_t seg_t0, int n_samples) {                  // whisper.cpp:8378-8383
+    const int sample = (int) (((t - seg_t0) * WHISPER_SAMPLE_RATE) / 100);
+    return std::max(0, std::min(n_samples - 1, sample));
+}
+int64_t sample_to_ts(int i_sample, int64_t seg_t0) { return (100ll * i_sample) / WHISPER_SAMPLE_RATE + seg_t0; }
+
+void token_level_timestamps(whisper_context * ctx, whisper_state * st, int i_segment, float thold_pt, float thold_ptsum) {   // whisper.cpp:8391-8616
+    auto & segment = st->result_all[i_segment];
+    auto & tokens = segment.tokens;
+    const int n_samples = (int) st->energy.size();
+    if (n_samples == 0) { WA_ERROR("%s: no signal data available\n", __func__); return; }
+    const int64_t t0 = segment.t0, t1 = segment.t1;
+    const int n = (int) tokens.size();
+    if (n == 0) return;
+    if (n == 1) { tokens[0].t0 = t0; tokens[0].t1 = t1; return; }
+    const whisper_token beg = ctx->vocab.token_beg, eot = ctx->vocab.token_eot;
+    auto & t_beg = st->t_beg; auto & t_last = st->t_last; auto & tid_last = st->tid_last;
+
+    for (int j = 0; j < n; ++j) {
+        auto & token = tokens[j];
+        if (j == 0) {
+            if (token.id == beg) {
+                tokens[j].t0 = t0; tokens[j].t1 = t0; tokens[j + 1].t0 = t0;
+                t_beg = t0; t_last = t0; tid_last = beg;
+            } else tokens[j].t0 = t_last;
+        }
+        const int64_t tt = t_beg + 2 * (token.tid - beg);
+        tokens[j].vlen = voice_length(whisper_token_to_str(ctx, token.id));
+        if (token.pt > thold_pt && token.ptsum > thold_ptsum && token.tid > tid_last && tt <= t1) {
+            if (j > 0) tokens[j - 1].t1 = tt;
+            tokens[j].t0 = tt;
+            tid_last = token.tid;
+        }
+    }
+    tokens[n - 2].t1 = t1;
+    tokens[n - 1].t0 = t1;
+    tokens[n - 1].t1 = t1;
+    t_last = t1;
+
+    {   // stretches of tokens without a trusted timestamp: split the interval by voice length
+        int p0 = 0, p1 = 0;
+        while (true) {
+            while (p1 < n && tokens[p1].t1 < 0) p1++;
+            if (p1 >= n) p1--;
+            if (p1 > p0) {
+                double psum = 0.0;
+                for (int j = p0; j <= p1; j++) psum += tokens[j].vlen;
+                const double dt = tokens[p1].t1 - tokens[p0].t0;
+                for (int j = p0 + 1; j <= p1; j++) {
+                    const double ct = tokens[j - 1].t0 + dt * tokens[j - 1].vlen / psum;
+                    tokens[j - 1].t1 = ct;
+                    tokens[j].t0 = ct;
+                }
+            }
+            p1++;
+            p0 = p1;
+            if (p1 >= n) break;
+        }
+    }
+    for (int j = 0; j < n - 1; j++) {       // fix-ups
+        if (tokens[j].t1 < 0) tokens[j + 1].t0 = tokens[j].t1;
+        if (j > 0 && tokens[j - 1].t1 > tokens[j].t0) {
+            tokens[j].t0 = tokens[j - 1].t1;
+            tokens[j].t1 = std::max(tokens[j].t0, tokens[j].t1);
+        }
+    }
+    {   // expand or contract by voice activity
+        const int hw = WHISPER_SAMPLE_RATE / 8;
+        const std::vector<float> & energy = st->energy;
+        for (int j = 0; j < n; j++) {
+            if (tokens[j].id >= eot) continue;
+            int s0 = ts_to_sample(tokens[j].t0, segment.t0, n_samples);
+            int s1 = ts_to_sample(tokens[j].t1, segment.t0, n_samples);
+            const int ss0 = std::max(s0 - hw, 0), ss1 = std::min(s1 + hw, n_samples);
+            const int ns = ss1 - ss0;
+            float sum = 0.0f;
+            for (int k = ss0; k < ss1; k++) sum += energy[k];
+            const float thold = 0.5 * sum / ns;
+            {
+                int k = s0;
+                if (energy[k] > thold && j > 0) {
+                    while (k > 0 && energy[k] > thold) k--;
+                    tokens[j].t0 = sample_to_ts(k, segment.t0);
+                    if (tokens[j].t0 < tokens[j - 1].t1) tokens[j].t0 = tokens[j - 1].t1;
+                    else s0 = k;
+                } else {
+                    while (energy[k] < thold && k < s1) k++;
+                    s0 = k;
+                    tokens[j].t0 = sample_to_ts(k, segment.t0);
+                }
+            }
+            {
+                int k = s1;
+                if (energy[k] > thold) {
+                    while (k < n_samples - 1 && energy[k] > thold) k++;
+                    tokens[j].t1 = sample_to_ts(k, segment.t0);
+                    if (j < n - 1 && tokens[j].t1 > tokens[j + 1].t0) tokens[j].t1 = tokens[j + 1].t0;
+                    else s1 = k;
+                } else {
+                    while (energy[k] < thold && k > s0) k--;
+                    s1 = k;
+                    tokens[j].t1 = sample_to_ts(k, segment.t0);
+                }
+            }
+        }
+    }
+}
+
+// wrap the last segment to max_len characters; returns the number of segments it became (whisper.cpp:6047-6100)
+int wrap_segment(whisper_context * ctx, whisper_state * st, int max_len, bool split_on_word) {
+    wa_segment segment = st->result_all.back();
+    int res = 1, acc = 0;
+    std::string text;
+    for (int i = 0; i < (int) segment.tokens.size(); i++) {
+        const auto & token = segment.tokens[i];
+        if (token.id >= ctx->vocab.token_eot) continue;
+        const char * txt = whisper_token_to_str(ctx, token.id);
+        const int cur = (int) strlen(txt);
+        if (acc + cur > max_len && i > 0 && (!split_on_word || txt[0] == ' ')) {
+            auto & last = st->result_all.back();
+            last.text = std::move(text);
+            last.t1 = token.t0;
+            last.tokens.resize(i);
+            last.speaker_turn_next = false;
+            wa_segment next;
+            next.t0 = token.t0; next.t1 = segment.t1;
+            next.tokens.assign(segment.tokens.begin() + i, segment.tokens.end());
+            next.speaker_turn_next = segment.speaker_turn_next;
+            st->result_all.push_back(std::move(next));
+            acc = 0;
+            text = "";
+            segment = st->result_all.back();
+            i = -1;
+            res++;
+        } else { acc += cur; text += txt; }
+    }
+    st->result_all.back().text = std::move(text);
+    return res;
+}
+
 struct beam_candidate { int decoder_idx; int seek_delta; bool has_ts; wa_sequence sequence; };
 
 bool same_tokens(const wa_sequence & a, const wa_sequence & b) {   // whisper.cpp:6419-6430
@@ -306,7 +477,20 @@ int runner::run(const float * samples, int n_samples) {
         WA_INFO("%s: auto-detected language: %s (p = %f)\n", __func__, p.language, probs[lang_id]);
         if (p.detect_language) return 0;
     }
-    if (p.token_timestamps) WA_WARN("%s: token_timestamps (signal-energy heuristic) is not implemented by this backend; use DTW\n", __func__);
+    if (p.token_timestamps) {                       // whisper.cpp:6832-6839
+        st->t_beg = 0; st->t_last = 0; st->tid_last = 0;
+        if (n_samples > 0) {
+            std::vector<float> host;
+            const float * pcm = samples;
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, samples) == hipSuccess && attr.type == hipMemoryTypeDevice) {    // PCM handed over in HBM
+                host.resize(n_samples);
+                if (!WA_HIP_OK(hipMemcpy(host.data(), samples, (size_t) n_samples * sizeof(float), hipMemcpyDeviceToHost))) return -2;
+                pcm = host.data();
+            } else (void) hipGetLastError();
+            st->energy = signal_energy(pcm, n_samples, 32);
+        }
+    }
     if (p.n_grammar_rules > 0) WA_WARN("%s: grammar sampling is not implemented by this backend; rules ignored\n", __func__);
 
     const int seek_start = p.offset_ms / 10;
@@ -645,7 +829,12 @@ int runner::run(const float * samples, int n_samples) {
                 seg.t0 = t0; seg.t1 = t1; seg.text = text; seg.no_speech_prob = st->no_speech_prob; seg.speaker_turn_next = speaker_turn_next;
                 for (int j = i0; j < i1; ++j) seg.tokens.push_back(tokens_cur[j]);
                 result_all.push_back(std::move(seg));
-                if (p.new_segment_callback && !ctx->params.dtw_token_timestamps) p.new_segment_callback(ctx, st, 1, p.new_segment_callback_user_data);
+                int n_new = 1;
+                if (p.token_timestamps) {                   // whisper.cpp:7619-7626
+                    token_level_timestamps(ctx, st, (int) result_all.size() - 1, p.thold_pt, p.thold_ptsum);
+                    if (p.max_len > 0) n_new = wrap_segment(ctx, st, p.max_len, p.split_on_word);
+                }
+                if (p.new_segment_callback && !ctx->params.dtw_token_timestamps) p.new_segment_callback(ctx, st, n_new, p.new_segment_callback_user_data);
             };
 
             if (!tokens_cur.empty() && ctx->model.n_loaded > 0 && !is_no_speech) {

@@ -260,6 +260,11 @@ struct whisper_state {
     float no_speech_prob = 0.0f;
     int32_t exp_n_audio_ctx = 0;
 
+    // heuristic token timestamps (ref: whisper.cpp:937-942): carried from segment to segment within one call
+    int64_t t_beg = 0, t_last = 0;
+    whisper_token tid_last = 0;
+    std::vector<float> energy;             // PCM signal energy
+
     // DTW (ref: whisper.cpp:856-860, 946-948)
     std::vector<std::vector<int>> aheads;  // per text layer: list of heads
     std::vector<int> aheads_slot;          // per text layer: slot in d_aheads_qk during the DTW pass (-1: none)

@@ -471,6 +471,7 @@ class WhisperState:
                             p=[t.p for t in toks], plog=[t.plog for t in toks],
                             pt=[t.pt for t in toks], ptsum=[t.ptsum for t in toks],
                             t_dtw=[t.t_dtw for t in toks],
+                            tok_t0=[t.t0 for t in toks], tok_t1=[t.t1 for t in toks], vlen=[t.vlen for t in toks],
                             no_speech_prob=self.full_get_segment_no_speech_prob(i)))
         return out
 
