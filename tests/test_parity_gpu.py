@@ -347,3 +347,45 @@ def test_heuristic_token_timestamps_and_segment_wrap_match_reference(wrs, amd_li
                 assert a == b, (tag, aseed, a, b)
             st.free()
     ctx.free()
+
+
+def test_full_parallel_is_the_concatenation_of_its_parts(wrs, amd_lib):
+    """whisper_full_parallel (whisper.cpp:7736-7864) with n_processors = 2: the result on the context's own state equals
+    transcribing the two halves separately, the second half shifted by the cut and clamped to start after the first ends."""
+    lib = amd_lib
+    mp = wsynth.model_path("s128").encode()
+    cp = wrs.WhisperContextParameters(lib)
+    lib.whisper_init_from_file_with_params.restype = C.c_void_p
+    lib.whisper_init_from_file_with_params.argtypes = [C.c_char_p, type(cp.c)]
+    fp = wrs.FullParams(lib, 0, best_of=1, temperature_inc=0.0)
+    lib.whisper_full_parallel.restype = C.c_int
+    lib.whisper_full_parallel.argtypes = [C.c_void_p, type(fp.c), C.POINTER(C.c_float), C.c_int, C.c_int]
+    for f, rt in (("whisper_full_n_segments", C.c_int), ("whisper_full_get_segment_t0", C.c_int64), ("whisper_full_get_segment_t1", C.c_int64)):
+        getattr(lib, f).restype = rt
+    lib.whisper_full_n_segments.argtypes = [C.c_void_p]
+    lib.whisper_full_get_segment_t0.argtypes = [C.c_void_p, C.c_int]; lib.whisper_full_get_segment_t1.argtypes = [C.c_void_p, C.c_int]
+    lib.whisper_full_n_tokens.restype = C.c_int; lib.whisper_full_n_tokens.argtypes = [C.c_void_p, C.c_int]
+    lib.whisper_full_get_token_id.restype = C.c_int; lib.whisper_full_get_token_id.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.whisper_free.argtypes = [C.c_void_p]
+    pcm = wsynth.synth_audio(960000, 4)       # 60 s: two 30 s halves
+    ctxp = lib.whisper_init_from_file_with_params(mp, cp.c)
+    assert ctxp
+    rc = lib.whisper_full_parallel(ctxp, fp.c, pcm.ctypes.data_as(C.POINTER(C.c_float)), len(pcm), 2)
+    assert rc == 0
+    got = [(lib.whisper_full_get_segment_t0(ctxp, i), lib.whisper_full_get_segment_t1(ctxp, i),
+            [lib.whisper_full_get_token_id(ctxp, i, j) for j in range(lib.whisper_full_n_tokens(ctxp, i))]) for i in range(lib.whisper_full_n_segments(ctxp))]
+    lib.whisper_free(ctxp)
+    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), cp, lib=lib)
+    want = []
+    half = len(pcm) // 2
+    for k, part in enumerate((pcm[:half], pcm[half:])):
+        st = ctx.create_state()
+        st.full(fp, np.ascontiguousarray(part))
+        for s in st.segments():
+            t0, t1 = s["t0"] + k * (100 * half // 16000), s["t1"] + k * (100 * half // 16000)
+            if want:
+                t0 = max(t0, want[-1][1])
+            want.append((t0, t1, s["ids"]))
+        st.free()
+    ctx.free()
+    assert got == want and len(got) > 0

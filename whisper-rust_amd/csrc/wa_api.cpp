@@ -581,10 +581,57 @@ int whisper_full(struct whisper_context * ctx, struct whisper_full_params params
     return whisper_full_with_state(ctx, ctx->state, params, samples, n_samples);
 }
 int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples, int n_processors) {
-    // ref: whisper.cpp:7736-7864.  n_processors == 1 is the only form whisper-rs-era callers use here;
-    // chunk-parallel processing on this backend is whisper_amd_full_batch / one process per GPU.
-    if (n_processors != 1) WA_WARN("%s: n_processors=%d is not supported, running as 1\n", __func__, n_processors);
-    return whisper_full(ctx, params, samples, n_samples);
+    // ref: whisper.cpp:7736-7864: the audio is cut into n_processors equal parts, each transcribed on a state of its own (here:
+    // concurrently on this device, one HIP stream each), the segment lists appended with their time offsets.  As in the reference
+    // the transcription may be degraded near the cuts.
+    if (!ctx || !ctx->state) return -1;
+    if (n_processors <= 1) return whisper_full(ctx, params, samples, n_samples);
+    if (params.vad) { WA_ERROR("%s: VAD is not supported by this backend\n", __func__); return -1; }
+    const int offset_samples = (WHISPER_SAMPLE_RATE * params.offset_ms) / 1000;
+    const int n_per = (n_samples - offset_samples) / n_processors;
+    std::vector<whisper_state *> states;
+    std::vector<std::thread> workers;
+    std::vector<int> rcs(n_processors, 0);
+    const bool mega0 = ctx->state->mega_enabled;
+    ctx->state->mega_enabled = false;               // several chunks in flight: the launch sequence overlaps better (see whisper_amd_full_batch)
+    for (int i = 0; i < n_processors - 1; ++i) {
+        whisper_state * st = whisper_init_state(ctx);
+        if (!st) { for (auto & w : workers) w.join(); for (auto * s2 : states) whisper_free_state(s2); ctx->state->mega_enabled = mega0; return -1; }
+        st->mega_enabled = false;
+        states.push_back(st);
+        const int start = offset_samples + (i + 1) * n_per;
+        const int n_cur = (i == n_processors - 2) ? n_samples - start : n_per;
+        whisper_full_params pc = params;
+        pc.offset_ms = 0; pc.print_progress = false; pc.print_realtime = false;
+        pc.new_segment_callback = nullptr; pc.new_segment_callback_user_data = nullptr;
+        pc.progress_callback = nullptr; pc.progress_callback_user_data = nullptr;
+        workers.emplace_back([=, &rcs]() { rcs[i + 1] = whisper_full_with_state(ctx, st, pc, samples + start, n_cur); });
+    }
+    {
+        whisper_full_params pc = params;
+        pc.print_realtime = false;
+        rcs[0] = whisper_full_with_state(ctx, ctx->state, pc, samples, offset_samples + n_per);
+    }
+    for (auto & w : workers) w.join();
+    ctx->state->mega_enabled = mega0;
+    const int64_t offset_t = (int64_t) params.offset_ms / 10.0;
+    for (int i = 0; i < n_processors - 1; ++i) {
+        for (auto & r : states[i]->result_all) {
+            r.t0 += 100 * ((i + 1) * n_per) / WHISPER_SAMPLE_RATE + offset_t;
+            r.t1 += 100 * ((i + 1) * n_per) / WHISPER_SAMPLE_RATE + offset_t;
+            if (!ctx->state->result_all.empty()) r.t0 = std::max(r.t0, ctx->state->result_all.back().t1);    // no overlapping segments
+            ctx->state->result_all.push_back(std::move(r));
+            if (params.new_segment_callback) params.new_segment_callback(ctx, ctx->state, 1, params.new_segment_callback_user_data);
+        }
+        ctx->state->t_mel_us += states[i]->t_mel_us; ctx->state->t_sample_us += states[i]->t_sample_us; ctx->state->t_encode_us += states[i]->t_encode_us;
+        ctx->state->t_decode_us += states[i]->t_decode_us; ctx->state->t_batchd_us += states[i]->t_batchd_us; ctx->state->t_prompt_us += states[i]->t_prompt_us;
+        ctx->state->n_sample += states[i]->n_sample; ctx->state->n_encode += states[i]->n_encode; ctx->state->n_decode += states[i]->n_decode;
+        ctx->state->n_batchd += states[i]->n_batchd; ctx->state->n_prompt += states[i]->n_prompt;
+        whisper_free_state(states[i]);
+    }
+    ctx->state->t_mel_us /= n_processors; ctx->state->t_sample_us /= n_processors; ctx->state->t_encode_us /= n_processors; ctx->state->t_decode_us /= n_processors;
+    WA_WARN("%s: the audio has been split into %d chunks; the transcription quality may be degraded near the boundaries\n", __func__, n_processors);
+    return rcs[0];
 }
 
 // -------------------------------------------------------------------------------------------------
