@@ -389,3 +389,39 @@ def test_full_parallel_is_the_concatenation_of_its_parts(wrs, amd_lib):
         st.free()
     ctx.free()
     assert got == want and len(got) > 0
+
+
+@pytest.mark.parametrize("qt", ["q5_0", "q8_0"])
+def test_quantised_models_bit_exact(wrs, amd_lib, qt):
+    """BASELINE config 5's weight format: a Q5_0 / Q8_0 model file (quantised by the reference's own tool) through the quantised
+    products of wa_quant.hip - encoder output and teacher-forced logits bit-identical to the reference engine (digests), identical
+    segments / ids / p / plog for greedy, the temperature ladder and beam search (goldens: tools/gen_golden_quant.py)."""
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import gen_golden_quant as g
+    gold = json.load(open(os.path.join(GOLDEN, "s128_quant.json")))[qt]
+    mp = wsynth.quant_model_path("s128", qt)
+    assert hashlib.sha256(open(mp, "rb").read()).hexdigest() == gold["model_sha256"], "the quantised model file differs from the goldens'"
+    ctx = wrs.WhisperContext.new_with_params(mp, wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    d = ctx.model_n_audio_state()
+    st = ctx.create_state()
+    st.pcm_to_mel(wsynth.synth_audio(480000, 0)); st.encode(0)
+    assert digest(_get(amd_lib, "whisper_amd_get_embd_enc", st, 1500 * d)) == gold["embd_enc"]["sha256"]
+    for e in gold["logits"]:
+        st.decode(e["tokens"], e["n_past"])
+        lg = st.get_logits_last(len(e["tokens"]))
+        assert digest(lg) == e["sha256"], "logits %r n_past %d: top %d vs %d" % (e["tokens"][:3], e["n_past"], int(np.argmax(lg)), e["top"])
+    st.free()
+    for tag, kw in g.FULL.items():
+        for aseed in (0, 1):
+            st = ctx.create_state()
+            kk = {k: v for k, v in kw.items() if k != "strategy"}
+            st.full(wrs.FullParams(amd_lib, kw.get("strategy", 0), **kk), wsynth.synth_audio(480000, aseed))
+            try:
+                _same(_segs(st), gold["full"]["%s_seed%d" % (tag, aseed)])
+            except AssertionError as ex:
+                raise AssertionError("%s %s seed %d: %s" % (qt, tag, aseed, ex))
+            st.free()
+    ctx.free()

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Golden vectors for quantised models (BASELINE config 5's weight format): the REFERENCE ENGINE itself on the s128 synthetic
+model quantised to Q5_0 and Q8_0 by the reference's own quantizer.  Digests of the encoder output and of teacher-forced logits,
+and full transcriptions (greedy, temperature ladder, beam).  Run in the build container; writes tests/golden/s128_quant.json."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "whisper-rust_amd"))
+import wsynth  # noqa: E402
+import whisper_rs as W  # noqa: E402
+
+QTYPES = ("q5_0", "q8_0")
+SEQS = [([50258, 50259, 50359], 0), ([50369], 3), ([1234], 4), ([4321, 777, 31000, 15, 50], 5), ([220], 10), (list(range(1000, 1040)), 11), ([7], 51)]
+FULL = {
+    "greedy": dict(strategy=0, best_of=1, temperature_inc=0.0),
+    "ladder": dict(strategy=0, best_of=2, temperature_inc=0.2),
+    "beam3": dict(strategy=1, beam_size=3, best_of=2, temperature_inc=0.0),
+}
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def segs(st):
+    return [dict(t0=s["t0"], t1=s["t1"], text=s["text"].decode("latin1"), ids=s["ids"], tids=s["tids"],
+                 p=[float(np.float32(x)) for x in s["p"]], plog=[float(np.float32(x)) for x in s["plog"]]) for s in st.segments()]
+
+
+if __name__ == "__main__":
+    ref = W.load_library(os.path.join(ROOT, "oracle", "_ref", "libwhisper_ref.so"))
+    W.set_log_callback(ref, None)
+    ref.ref_shim_get_embd_enc.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    gold = {}
+    for qt in QTYPES:
+        mp = wsynth.quant_model_path("s128", qt)
+        ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(ref, use_gpu=False), lib=ref)
+        d = ctx.model_n_audio_state()
+        g = dict(model_bytes=os.path.getsize(mp), model_sha256=hashlib.sha256(open(mp, "rb").read()).hexdigest())
+        st = ctx.create_state()
+        st.pcm_to_mel(wsynth.synth_audio(480000, 0), 4); st.encode(0, 8)
+        x = np.empty(1500 * d, np.float32)
+        ref.ref_shim_get_embd_enc(st.ptr, x.ctypes.data_as(C.POINTER(C.c_float)), x.size)
+        g["embd_enc"] = dict(sha256=digest(x), absmax=float(np.abs(x).max()))
+        g["logits"] = []
+        for toks, n_past in SEQS:
+            st.decode(toks, n_past, 8)
+            lg = st.get_logits_last(len(toks))
+            g["logits"].append(dict(tokens=toks, n_past=n_past, sha256=digest(lg), absmax=float(np.abs(lg).max()), top=int(np.argmax(lg))))
+        st.free()
+        g["full"] = {}
+        for tag, kw in FULL.items():
+            for aseed in (0, 1):
+                st = ctx.create_state()
+                kk = {k: v for k, v in kw.items() if k != "strategy"}
+                st.full(W.FullParams(ref, kw.get("strategy", 0), n_threads=8, **kk), wsynth.synth_audio(480000, aseed))
+                g["full"]["%s_seed%d" % (tag, aseed)] = segs(st)
+                st.free()
+        gold[qt] = g
+        ctx.free()
+        print(qt, "done", {k: len(v) for k, v in g["full"].items()})
+    json.dump(gold, open(os.path.join(ROOT, "tests", "golden", "s128_quant.json"), "w"), indent=1)

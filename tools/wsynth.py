@@ -203,6 +203,22 @@ def model_path(shape_name: str, seed: int = 0, cache_dir: str | None = None) -> 
     return p
 
 
+def quant_model_path(shape_name: str, qtype: str, seed: int = 0, cache_dir: str | None = None) -> str:
+    """Path of the cached Q5_0 / Q8_0 version of a synthetic model, produced on first use by the REFERENCE's own quantizer
+    (examples/quantize, compiled by oracle/Makefile into oracle/_ref/quantize-ref; test infrastructure only)."""
+    import subprocess
+    src = model_path(shape_name, seed, cache_dir)
+    dst = src[:-4] + "-" + qtype + ".bin"
+    if not os.path.exists(dst):
+        tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "quantize-ref")
+        if not os.path.exists(tool):
+            raise FileNotFoundError("oracle/_ref/quantize-ref missing (make -C oracle ref)")
+        tmp = dst + ".tmp%d" % os.getpid()
+        subprocess.run([tool, src, tmp, qtype], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.replace(tmp, dst)
+    return dst
+
+
 # --------------------------------------------------------------------------------------------------
 # audio
 # --------------------------------------------------------------------------------------------------

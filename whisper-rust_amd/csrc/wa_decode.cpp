@@ -161,6 +161,56 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
     }
 }
 
+// The same pass for a quantised model (Q5_0 / Q8_0 weights, wa_quant.hip): every product quantises its F32 operand row to Q8_0
+// first, so LayerNorm, attention and GELU hand over F32.  Eager launches (no graph, no one-launch step).
+static void decode_launch_quant(whisper_context & ctx, whisper_state & st, int n_tokens, int n_kv, int kv_head, const int8_t * mask, int n_rows,
+                                const int32_t * h_rows, bool save_aheads) {
+    const auto & m  = ctx.model;
+    const auto & hp = m.hp;
+    auto & kv = st.kv_self;
+    const int n_vocab = hp.n_vocab, d = hp.n_text_state, H = hp.n_text_head;
+    const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
+    hipStream_t s = st.stream;
+    auto qlin = [&](wa_epi_mode mode, const float * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
+        wa_launch_quantize_q8_0(s, A, lda, M, L.n_in, st.d_q8, st.d_q8d);
+        wa_launch_qgemm_exact(s, mode, st.d_q8, st.d_q8d, M, L.wtype, L.qs, L.qh, L.qd, L.n_out, L.n_in, e);
+    };
+    wa_launch_dec_embed_q(s, st.d_tok, st.d_pos, n_tokens, d, m.te_q.wtype, m.te_q.qs, m.te_q.qh, m.te_q.qd, m.d_pe, st.d_dx);
+    const float KQscale = pow(float(64), -0.25);
+    const size_t kv_layer = (size_t) kv.size * d, cross_layer = (size_t) H * st.cross_tpad * 64;
+    for (int il = 0; il < hp.n_text_layer; ++il) {
+        const auto & L = m.dec[il];
+        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.attn_ln.w, L.attn_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
+        {
+            wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
+            e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
+            e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
+            qlin(WA_EPI_DEC_QKV, st.d_q32a, d, L.qkv, n_tokens, e);
+        }
+        wa_launch_attn_exact(s, st.d_dq, d, kv.k + il * kv_layer, 64, d, kv.v + il * kv_layer, 64, d, H, n_tokens, n_kv, mask, 1.0f,
+                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr, nullptr, st.d_q32a);
+        { wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32a, d, L.out, n_tokens, e); }
+        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.cross_ln.w, L.cross_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
+        { wa_epi e; e.bias = L.cross_q.b; e.out = st.d_dq; e.ldo = d; qlin(WA_EPI_F16, st.d_q32a, d, L.cross_q, n_tokens, e); }
+        float * qk_out = nullptr;
+        if (save_aheads && st.d_aheads_qk && il < (int) st.aheads_slot.size() && st.aheads_slot[il] >= 0)
+            qk_out = st.d_aheads_qk + (size_t) st.aheads_slot[il] * n_tokens * H * T;
+        wa_launch_attn_exact(s, st.d_dq, d, st.d_cross_k + il * cross_layer, (size_t) st.cross_tpad * 64, 64, st.d_cross_v + il * cross_layer,
+                             (size_t) st.cross_tpad * 64, 64, H, n_tokens, T, nullptr, KQscale, st.d_att_partial, st.d_att_pleft, st.d_dao, d, qk_out,
+                             nullptr, st.d_q32a);
+        { wa_epi e; e.bias = L.cross_out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32a, d, L.cross_out, n_tokens, e); }
+        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
+        { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_q32b; e.ldo = 4 * d; qlin(WA_EPI_GELU_F32, st.d_q32a, d, L.fc1, n_tokens, e); }
+        { wa_epi e; e.bias = L.fc2.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32b, 4 * d, L.fc2, n_tokens, e); }
+    }
+    if (n_rows) {       // final LayerNorm of the flagged rows (packed), then the logits product over the quantised token embedding
+        for (int i = 0; i < n_rows; ++i)
+            wa_launch_layernorm_exact(s, st.d_dx + (size_t) h_rows[i] * d, d, 1, d, m.d_ln.w, m.d_ln.b, hp.eps, nullptr, 0, st.d_q32a + (size_t) i * d, d);
+        wa_epi e; e.out = st.d_logits; e.ldo = n_vocab;
+        qlin(WA_EPI_F32, st.d_q32a, d, m.te_q, n_rows, e);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // the single-token pass as ONE launch (wa_mega.hip).  Only one such launch may be in flight per device: its
 // workgroups wait for each other, so two of them interleaved by the dispatcher could each hold CUs the other needs.
@@ -357,7 +407,9 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     if (n_rows) (void) hipMemcpyAsync(st.d_rows, h_rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice, s);
     (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
 
-    if (st.graphs_enabled && steady) {
+    if (m.wtype != 1) {
+        decode_launch_quant(ctx, st, n_tokens, n_kv, kv_head, need_mask ? st.d_mask : nullptr, n_rows, h_rows, save_aheads);
+    } else if (st.graphs_enabled && steady) {
         const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx;
         if (st.dec_graph && (st.dec_graph_T != T || st.dec_graph_kv_size != kv.size || st.dec_graph_kv_k != kv.k)) {
             (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr;
@@ -438,14 +490,19 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     h[3] = n_past + 1; h[4] = n_past;
     (void) hipMemcpyAsync(st->d_dyn, h + 3, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s);
     hipGraphExec_t ge = nullptr;
-    if (st->graphs_enabled) {
+    if (st->graphs_enabled && ctx->model.wtype == 1) {
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false, st->d_dyn);
             if (hipStreamEndCapture(s, &g) == hipSuccess && g) { if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr; (void) hipGraphDestroy(g); }
         }
     }
-    auto one = [&]() { if (ge) (void) hipGraphLaunch(ge, s); else decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false); };
+    const int32_t row0 = 0;
+    auto one = [&]() {
+        if (ctx->model.wtype != 1) decode_launch_quant(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, &row0, false);
+        else if (ge) (void) hipGraphLaunch(ge, s);
+        else decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false);
+    };
     one();      // warm-up
     (void) hipEventRecord(e0, s);
     for (int i = 0; i < n_iters; ++i) one();
@@ -492,7 +549,7 @@ extern "C" int whisper_amd_mega_enabled(struct whisper_state * st) { return st &
 // layout of whisper_amd_mega_debug (values only: F32 bits, or two F16 per word) - to localise a difference.
 extern "C" int whisper_amd_seq_debug(struct whisper_context * ctxp, struct whisper_state * stp, int token, int n_past, unsigned * values_out,
                                      float * logits_out) {
-    if (!ctxp || !stp) return -1;
+    if (!ctxp || !stp || ctxp->model.wtype != 1) return -1;
     whisper_context & ctx = *ctxp; whisper_state & st = *stp;
     if (!WA_HIP_OK(hipSetDevice(ctx.device))) return -1;
     const auto & m = ctx.model; const auto & hp = m.hp;

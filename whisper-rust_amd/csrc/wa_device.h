@@ -119,6 +119,8 @@ __device__ __forceinline__ void epi_apply(const wa_epi & e, int m, int n, float 
         else              ((wa_f16 *) e.out2)[(size_t) (n - e.split0) * e.ldo2 + m] = f2h(v);
     } else if (EPI == WA_EPI_GELU_F16) {
         ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(wa_gelu(v, e.gelu));
+    } else if (EPI == WA_EPI_GELU_F32) {
+        ((float *) e.out)[(size_t) m * e.ldo + n] = wa_gelu(v, e.gelu);
     } else if (EPI == WA_EPI_RESID) {
         ((float *) e.out)[(size_t) m * e.ldo + n] = v + p.resid;
     } else if (EPI == WA_EPI_CONV2) {

@@ -98,6 +98,10 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
         }
     }
     if (!dev_alloc(st.d_att_partial, (size_t) 512 * 32 * 64) || !dev_alloc(st.d_att_pleft, (size_t) 512 * 32)) return false;
+    if (ctx.model.wtype != 1) {
+        if (!dev_alloc(st.d_q32a, (size_t) tpad * d) || !dev_alloc(st.d_q32b, (size_t) tpad * 4 * d) || !dev_alloc(st.d_q8, (size_t) tpad * 4 * d) ||
+            !dev_alloc(st.d_q8d, (size_t) tpad * 4 * d / 32)) return false;
+    }
     if (!dev_alloc(st.d_im2col, std::max((size_t) 2 * T * 3 * hp.n_mels, (size_t) T * 3 * d) + 64)) return false;
     if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_stage_i32, (size_t) 4 * mpad * sizeof(int32_t)))) return false;
     st.h_logits_cap = (size_t) WA_MAX_DECODERS * hp.n_vocab + 64;
@@ -124,6 +128,7 @@ void wa_state_release(whisper_state & st) {
     dev_free(st.d_tok); dev_free(st.d_pos); dev_free(st.d_cell); dev_free(st.d_rows); dev_free(st.d_mask);
     dev_free(st.d_dx); dev_free(st.d_dxn); dev_free(st.d_dqkv); dev_free(st.d_dao); dev_free(st.d_dff); dev_free(st.d_dq);
     if (st.dec_graph) { (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr; }
+    dev_free(st.d_q32a); dev_free(st.d_q32b); dev_free(st.d_q8); dev_free(st.d_q8d);
     dev_free(st.d_mega_gr); dev_free(st.d_mega_cgr); dev_free(st.d_mega_out); st.d_mega_status = nullptr;
     dev_free(st.d_mega_out2); dev_free(st.d_mega_smask);
     for (int b = 0; b < 2; ++b) {
@@ -228,7 +233,7 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
     // Two interchangeable implementations of every dense product:
     //   exact (flash_attn == false): reference summation order on the VALU -> bit-identical to whisper.cpp CPU
     //   fast  (flash_attn == true) : MFMA (v_mfma_f32_16x16x32_f16), same rounding points, different F32 order
-    const bool exact = ctx.exact;
+    const bool exact = ctx.exact || m.wtype != 1;       // (quantised models: the conv stem stays F16 and runs in the reference order)
     auto gemm = [&](wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
         if (exact) wa_launch_gemm_exact(s, mode, A, lda, W, ldw, M, N, K, e);
         else       wa_launch_gemm(s, mode, A, lda, W, ldw, M, N, K, e);
@@ -256,6 +261,30 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
     }
 
     const float KQscale = 1.0f / sqrtf(float(64));    // whisper.cpp:2087
+    if (m.wtype != 1) {
+        // Quantised model: every 2-D weight is Q5_0 / Q8_0 and the reference multiplies it with the Q8_0 form of the F32
+        // activation row (wa_quant.hip).  Same sequence as below; the operands of the products stay F32 until they are quantised.
+        auto qlin = [&](wa_epi_mode mode, const float * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
+            wa_launch_quantize_q8_0(s, A, lda, M, L.n_in, st.d_q8, st.d_q8d);
+            wa_launch_qgemm_exact(s, mode, st.d_q8, st.d_q8d, M, L.wtype, L.qs, L.qh, L.qd, L.n_out, L.n_in, e);
+        };
+        for (int il = 0; il < hp.n_audio_layer; ++il) {
+            const auto & L = m.enc[il];
+            wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
+            { wa_epi e; e.bias = L.qkv.b; e.out = st.d_ff; e.ldo = 3 * d; qlin(WA_EPI_F16, st.d_q32a, d, L.qkv, T, e); }
+            wa_launch_attn_exact(s, st.d_ff, 3 * d, st.d_ff + d, 64, 3 * d, st.d_ff + 2 * d, 64, 3 * d, H, T, T, nullptr, KQscale,
+                                 st.d_att_partial, st.d_att_pleft, st.d_ao, d, nullptr, nullptr, st.d_q32a);
+            { wa_epi e; e.bias = L.out.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32a, d, L.out, T, e); }
+            wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
+            { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_q32b; e.ldo = 4 * d; qlin(WA_EPI_GELU_F32, st.d_q32a, d, L.fc1, T, e); }
+            { wa_epi e; e.bias = L.fc2.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32b, 4 * d, L.fc2, T, e); }
+        }
+        wa_launch_layernorm_exact(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, nullptr, 0, st.d_embd_enc, d);
+        {
+            wa_epi e; e.bias = m.cross_kv.b; e.scale = m.cross_kv.s; e.out = st.d_cross_k; e.out2 = st.d_cross_v; e.aux0 = st.cross_tpad; e.aux1 = d;
+            qlin(WA_EPI_CROSS_KV, st.d_embd_enc, d, m.cross_kv, T, e);
+        }
+    } else {
     for (int il = 0; il < hp.n_audio_layer; ++il) {
         const auto & L = m.enc[il];
         wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
@@ -291,6 +320,7 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
     {
         wa_epi e; e.bias = m.cross_kv.b; e.scale = m.cross_kv.s; e.out = st.d_cross_k; e.out2 = st.d_cross_v; e.aux0 = st.cross_tpad; e.aux1 = d;
         gemm(WA_EPI_CROSS_KV, st.d_xn, d, m.cross_kv.w, d, T, hp.n_text_layer * 2 * d, d, e);
+    }
     }
     if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
     st.have_enc = true;

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
                                                             int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
                                                             int n_kv_arg, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
                                                             wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out,
-                                                            const int * __restrict__ dyn) {
+                                                            const int * __restrict__ dyn, float * __restrict__ out32) {
     constexpr int NW = ATT_THREADS / 64;
     const int n_kv = dyn ? dyn[0] : n_kv_arg;
     __shared__ float sc[ATT_MAXKV];
@@ -561,7 +561,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
             }
 #pragma unroll
             for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
-            out[(size_t) j * ldo + h * 64 + tid] = f2h((float) sumf);
+            if (out32) out32[(size_t) j * ldo + h * 64 + tid] = (float) sumf;
+            else out[(size_t) j * ldo + h * 64 + tid] = f2h((float) sumf);
         }
     } else {
         const size_t pb = ((size_t) j * n_head + h) * 32;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
 
 __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ partial, const wa_f16 * __restrict__ p_left,
                                                      const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride, int n_kv_arg,
-                                                     wa_f16 * __restrict__ out, int ldo, const int * __restrict__ dyn) {
+                                                     wa_f16 * __restrict__ out, int ldo, const int * __restrict__ dyn, float * __restrict__ out32) {
     const int j = blockIdx.x, h = blockIdx.y, n_head = gridDim.y, dh = threadIdx.x;
     const int n_kv = dyn ? dyn[0] : n_kv_arg;
     const size_t pb = ((size_t) j * n_head + h) * 32;
@@ -591,22 +592,23 @@ __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ 
     }
 #pragma unroll
     for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
-    out[(size_t) j * ldo + h * 64 + dh] = f2h((float) sumf);
+    if (out32) out32[(size_t) j * ldo + h * 64 + dh] = (float) sumf;
+    else out[(size_t) j * ldo + h * 64 + dh] = f2h((float) sumf);
 }
 
 void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
-                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn) {
+                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn, float * out32) {
     // few (token, head) pairs and a long key range (decode cross-attention): spread the 32 partial-sum chains over 4 blocks
     // per pair and finish in k_attn_combine; otherwise one block per pair finishes in LDS (encoder, prompt, self-attention)
     const bool split = (long) n_tokens * n_head < 512 && n_kv > 512;
     if (!split) {
         hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32);
     } else {
         hipLaunchKernelGGL((k_attn_exact<4>), dim3(n_head * 4, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32);
         hipLaunchKernelGGL(k_attn_combine, dim3(n_tokens, n_head), dim3(64), 0, s, partial, p_left, vbase, v_head_stride, v_row_stride, n_kv,
-                           out, ldo, dyn);
+                           out, ldo, dyn, out32);
     }
 }

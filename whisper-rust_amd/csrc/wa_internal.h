@@ -61,7 +61,13 @@ struct wa_vocab {         // ref: whisper.cpp:462-491
 typedef uint16_t wa_f16;  // raw IEEE half bits on the host side
 
 struct wa_ln  { const float * w = nullptr; const float * b = nullptr; };
-struct wa_lin { const wa_f16 * w = nullptr; const float * b = nullptr; const float * s = nullptr; int n_out = 0, n_in = 0; };
+// A linear layer.  F16 weights: w [n_out][n_in].  Quantised weights (ggml block formats, ggml-common.h:187-214; wtype = ggml type
+// 6 Q5_0 / 8 Q8_0) are kept structure-of-arrays per 32-element block: qs [n_out][n_in/32][16 or 32] quant bytes,
+// qh [n_out][n_in/32] fifth bits (Q5_0), qd [n_out][n_in/32] block scales widened from F16 to F32 (exact).
+struct wa_lin {
+    const wa_f16 * w = nullptr; const float * b = nullptr; const float * s = nullptr; int n_out = 0, n_in = 0;
+    int wtype = 1; const uint8_t * qs = nullptr; const uint32_t * qh = nullptr; const float * qd = nullptr;
+};
 
 struct wa_enc_layer {
     wa_ln  attn_ln, mlp_ln;
@@ -83,6 +89,7 @@ struct wa_model {
     int n_mel_filt = 0, n_fft_filt = 0;
     std::vector<float> filters;     // host copy [n_mel][n_fft]
     int n_loaded = 0;               // 0 => header/vocab-only test model (ref: whisper.cpp:1959-1960)
+    int wtype = 1;                  // ggml type of the 2-D weight matrices: 1 F16, 6 Q5_0, 8 Q8_0 (whisper.cpp:1567-1573)
 
     // ---- device (all inside `arena`) ----
     void * arena = nullptr; size_t arena_size = 0;
@@ -99,7 +106,8 @@ struct wa_model {
     wa_ln  e_ln;
     std::vector<wa_enc_layer> enc;
     const float  * d_pe = nullptr;        // [n_text_ctx][d]
-    const wa_f16 * d_te = nullptr;        // [n_vocab][d]
+    const wa_f16 * d_te = nullptr;        // [n_vocab][d]  (F16 models)
+    wa_lin te_q;                          // the same matrix of a quantised model
     wa_ln  d_ln;
     std::vector<wa_dec_layer> dec;
     wa_lin cross_kv;                      // fused over ALL decoder layers: [L*2d][d]; per column bias+scale
@@ -221,6 +229,11 @@ struct whisper_state {
     float  * d_logits = nullptr;  // [mpad][n_vocab] f32
     int32_t * d_rows = nullptr;   // [mpad] row indices that need logits
     float  * d_aheads_qk = nullptr; // DTW capture
+    // quantised models (wa_quant.hip): F32 operands of the quantised products and their Q8_0 form (shared by encoder and decoder)
+    float  * d_q32a = nullptr;      // [tpad][d]   LayerNorm / attention output
+    float  * d_q32b = nullptr;      // [tpad][4d]  GELU(fc1)
+    int8_t * d_q8   = nullptr;      // [tpad][4d]
+    float  * d_q8d  = nullptr;      // [tpad][4d / 32]
 
     // hipGraph of the single-token decoder pass (launch-bound inner loop); parameters that change per token live in d_dyn
     int32_t * d_dyn = nullptr;            // {n_kv, kv_head}

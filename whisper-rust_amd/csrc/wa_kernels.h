@@ -16,6 +16,7 @@ enum wa_epi_mode {
     WA_EPI_CONV2,       // out f32[m][n]            = resid[m][n] + gelu(acc + bias[n]);  dbg[m][n] = gelu(...)
     WA_EPI_F32,         // out f32[m][n]            = acc (+ bias[n])
     WA_EPI_CROSS_KV,    // n -> (layer, k|v, head, c): out/out2 f16 [layer][head][aux0 = tpad][64]
+    WA_EPI_GELU_F32,    // out f32[m][n]            = gelu_f16_table(acc + bias[n])      (quantised models: the next product quantises from F32)
     WA_EPI_DEC_QKV,     // n <  split0: out  f16[m][n]                        (scaled query)
                         // n <  split1: out2 f16[(row_off + m)][n - split0]   (scaled key  -> KV cell)
                         // else       : out3 f16[(row_off + m)][n - split1]   (value       -> KV cell)
@@ -96,4 +97,15 @@ void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int
 // partial: f32 [n_tokens][n_head][32][64], p_left: f16 [n_tokens][n_head][32] (used when n_tokens*n_head < 512).
 void wa_launch_attn_exact(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
-                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn_n_kv = nullptr);
+                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn_n_kv = nullptr,
+                          float * out32 = nullptr /* when set: the result in F32 [n_tokens][ldo] instead of F16 (quantised models) */);
+
+// ---- quantised weights (wa_quant.hip): ggml's Q5_0 / Q8_0 x Q8_0 products in the reference's AVX2 order ----
+// quantize_row_q8_0 (arch/x86/quants.c): x f32 [rows][ldx] -> qs int8 [rows][K], qd f32 [rows][K/32] (block scale, rounded through F16)
+void wa_launch_quantize_q8_0(hipStream_t stream, const float * x, int ldx, int rows, int K, int8_t * qs, float * qd);
+// C[M][N] = xq . Wq^T, ggml_vec_dot_q5_0_q8_0 / q8_0_q8_0 order; wtype 6 (Q5_0) or 8 (Q8_0); any M
+void wa_launch_qgemm_exact(hipStream_t stream, wa_epi_mode mode, const int8_t * xq, const float * xd, int M, int wtype, const uint8_t * wqs,
+                           const uint32_t * wqh, const float * wqd, int N, int K, const wa_epi & e);
+// token embedding rows of a quantised matrix (dequantize_row_q5_0 / q8_0) + positional embedding
+void wa_launch_dec_embed_q(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d, int wtype, const uint8_t * wqs,
+                           const uint32_t * wqh, const float * wqd, const float * pe, float * x);

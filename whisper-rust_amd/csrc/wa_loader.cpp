@@ -31,12 +31,14 @@ inline float gelu_f32(float x) {
 }
 
 struct slot {             // where a named tensor goes
-    int    kind;          // 0 raw copy, 1 conv weight re-order ([oc][ic][3] -> [oc][3][ic], row stride ld)
+    int    kind;          // 0 raw copy, 1 conv weight re-order ([oc][ic][3] -> [oc][3][ic], row stride ld),
+                          // 2 quantised blocks -> structure of arrays (off = quant bytes, off2 = fifth bits, off3 = scales)
     size_t off;           // byte offset in the arena
     int    type;          // expected ggml type: 0 f32, 1 f16
     int64_t ne[3];        // expected ne[] (fastest first)
     int    ld;            // kind 1: destination row stride in elements
     size_t off2 = 0;      // kind 1: byte offset of the second, unpermuted copy (ggml im2col order)
+    size_t off3 = 0;
     bool   seen = false;
 };
 
@@ -94,10 +96,12 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
             WA_ERROR("%s: invalid model (bad hparams)\n", __func__);
             return false;
         }
-        if (hp.ftype != 1) {
-            // ftype 0 (all-F32) aborts in the reference's own conv path; quantised
-            // types are the "next" row and not built yet.
-            WA_ERROR("%s: unsupported ftype %d (this backend currently loads F16 models, ftype=1)\n", __func__, hp.ftype);
+        // ftype % 1000 names the type of the 2-D weights (whisper.cpp:1567-1573; ggml_ftype: 1 F16, 7 Q8_0, 8 Q5_0).  ftype 0 (all-F32)
+        // aborts in the reference's own conv path; the other quantised formats are not built.
+        const int ft = hp.ftype % 1000;
+        model.wtype = ft == 1 ? 1 : ft == 8 ? 6 : ft == 7 ? 8 : -1;
+        if (model.wtype < 0) {
+            WA_ERROR("%s: unsupported ftype %d (this backend loads F16, Q5_0 and Q8_0 models)\n", __func__, hp.ftype);
             return false;
         }
     }
@@ -184,7 +188,19 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
     const size_t o_sincos  = ab.take(800 * F);
     const size_t o_gelu    = ab.take(65536 * H);
 
-    struct lin_off { size_t w, b, s; };
+    struct lin_off { size_t w, b, s; size_t qs = 0, qh = 0, qd = 0; };
+    const int QT = model.wtype;                                  // 1, 6 or 8
+    const size_t QSB = QT == 6 ? 16 : 32;                        // quant bytes per 32-element block
+    auto take_q = [&](lin_off & o, size_t n_out, size_t n_in) {  // SoA storage of a quantised [n_out][n_in] matrix
+        const size_t nb = n_out * (n_in / 32);
+        o.qs = ab.take(nb * QSB); o.qh = ab.take(nb * 4); o.qd = ab.take(nb * 4);
+    };
+    auto add_q = [&](const std::string & name, const lin_off & o, size_t row0, int64_t n_in, int64_t n_rows) {
+        const size_t b0 = row0 * (size_t) (n_in / 32);
+        slot s; s.kind = 2; s.off = o.qs + b0 * QSB; s.off2 = o.qh + b0 * 4; s.off3 = o.qd + b0 * 4; s.type = QT;
+        s.ne[0] = n_in; s.ne[1] = n_rows; s.ne[2] = 1; s.ld = 0;
+        slots[name] = s;
+    };
     struct ln_off  { size_t w, b; };
     auto take_ln = [&](const std::string & base) {
         ln_off o{ ab.take(d * F), ab.take(d * F) };
@@ -193,17 +209,23 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
         return o;
     };
     auto take_lin = [&](const std::string & base, int n_out, int n_in) {
-        lin_off o{ ab.take((size_t) n_out * n_in * H), ab.take(n_out * F), 0 };
-        add(base + ".weight", 0, o.w, 1, n_in, n_out, 1);
+        lin_off o{ QT == 1 ? ab.take((size_t) n_out * n_in * H) : 0, ab.take(n_out * F), 0 };
+        if (QT == 1) add(base + ".weight", 0, o.w, 1, n_in, n_out, 1);
+        else { take_q(o, n_out, n_in); add_q(base + ".weight", o, 0, n_in, n_out); }
         add(base + ".bias",   0, o.b, 0, n_out, 1, 1);
         return o;
     };
     // fused q|k|v block: [3d][d] weights + [3d] bias (+ [3d] scale, filled by us)
     auto take_qkv = [&](const std::string & base, bool with_scale) {
-        lin_off o{ ab.take((size_t) 3 * d * d * H), ab.take(3 * d * F), with_scale ? ab.take(3 * d * F) : 0 };
-        add(base + ".query.weight", 0, o.w,                         1, d, d, 1);
-        add(base + ".key.weight",   0, o.w + (size_t) d * d * H,     1, d, d, 1);
-        add(base + ".value.weight", 0, o.w + (size_t) 2 * d * d * H, 1, d, d, 1);
+        lin_off o{ QT == 1 ? ab.take((size_t) 3 * d * d * H) : 0, ab.take(3 * d * F), with_scale ? ab.take(3 * d * F) : 0 };
+        if (QT == 1) {
+            add(base + ".query.weight", 0, o.w,                         1, d, d, 1);
+            add(base + ".key.weight",   0, o.w + (size_t) d * d * H,     1, d, d, 1);
+            add(base + ".value.weight", 0, o.w + (size_t) 2 * d * d * H, 1, d, d, 1);
+        } else {
+            take_q(o, 3 * d, d);
+            add_q(base + ".query.weight", o, 0, d, d); add_q(base + ".key.weight", o, d, d, d); add_q(base + ".value.weight", o, 2 * d, d, d);
+        }
         add(base + ".query.bias",   0, o.b,             0, d, 1, 1);
         add(base + ".value.bias",   0, o.b + 2 * d * F, 0, d, 1, 1);
         return o;
@@ -236,14 +258,18 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
     }
 
     const size_t o_dpe = ab.take((size_t) hp.n_text_ctx * d * F);
-    const size_t o_dte = ab.take((size_t) hp.n_vocab * d * H);
+    const size_t o_dte = QT == 1 ? ab.take((size_t) hp.n_vocab * d * H) : 0;
+    lin_off o_teq{ 0, 0, 0 };
     add("decoder.positional_embedding",   0, o_dpe, 0, d, hp.n_text_ctx, 1);
-    add("decoder.token_embedding.weight", 0, o_dte, 1, d, hp.n_vocab, 1);
+    if (QT == 1) add("decoder.token_embedding.weight", 0, o_dte, 1, d, hp.n_vocab, 1);
+    else { take_q(o_teq, hp.n_vocab, d); add_q("decoder.token_embedding.weight", o_teq, 0, d, hp.n_vocab); }
     const ln_off o_dln = take_ln("decoder.ln");
 
     // cross k|v of all layers fused: rows [il*2d, il*2d+d) key, [il*2d+d, (il+1)*2d) value
-    const size_t o_ckv_w = ab.take((size_t) Ld * 2 * d * d * H), o_ckv_b = ab.take((size_t) Ld * 2 * d * F),
+    const size_t o_ckv_w = QT == 1 ? ab.take((size_t) Ld * 2 * d * d * H) : 0, o_ckv_b = ab.take((size_t) Ld * 2 * d * F),
                  o_ckv_s = ab.take((size_t) Ld * 2 * d * F);
+    lin_off o_ckvq{ 0, 0, 0 };
+    if (QT != 1) take_q(o_ckvq, (size_t) Ld * 2 * d, d);
 
     struct dec_off { ln_off attn_ln, cross_ln, mlp_ln; lin_off qkv, out, cq, cout, fc1, fc2; };
     std::vector<dec_off> dof(Ld);
@@ -255,8 +281,12 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
         dof[i].cross_ln = take_ln(p + "cross_attn_ln");
         dof[i].cq       = take_lin(p + "cross_attn.query", d, d);
         dof[i].cout     = take_lin(p + "cross_attn.out", d, d);
-        add(p + "cross_attn.key.weight",   0, o_ckv_w + ((size_t) i * 2 * d) * d * H,     1, d, d, 1);
-        add(p + "cross_attn.value.weight", 0, o_ckv_w + ((size_t) i * 2 * d + d) * d * H, 1, d, d, 1);
+        if (QT == 1) {
+            add(p + "cross_attn.key.weight",   0, o_ckv_w + ((size_t) i * 2 * d) * d * H,     1, d, d, 1);
+            add(p + "cross_attn.value.weight", 0, o_ckv_w + ((size_t) i * 2 * d + d) * d * H, 1, d, d, 1);
+        } else {
+            add_q(p + "cross_attn.key.weight", o_ckvq, (size_t) i * 2 * d, d, d); add_q(p + "cross_attn.value.weight", o_ckvq, (size_t) i * 2 * d + d, d, d);
+        }
         add(p + "cross_attn.value.bias",   0, o_ckv_b + ((size_t) i * 2 * d + d) * F,     0, d, 1, 1);
         dof[i].mlp_ln   = take_ln(p + "mlp_ln");
         dof[i].fc1      = take_lin(p + "mlp.0", 4 * d, d);
@@ -317,8 +347,20 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
             return false;
         }
         if (ttype != s.type) { WA_ERROR("%s: tensor '%s' has type %d in model file, expected %d\n", __func__, name.c_str(), ttype, s.type); return false; }
-        const size_t nbytes = (size_t) nelements * (s.type == 0 ? F : H);
-        if (s.kind == 0) {
+        const size_t nbytes = s.type == 6 ? (size_t) nelements / 32 * 22 : s.type == 8 ? (size_t) nelements / 32 * 34 : (size_t) nelements * (s.type == 0 ? F : H);
+        if (s.kind == 2) {        // block_q5_0 { f16 d; u32 qh; u8 qs[16] } / block_q8_0 { f16 d; i8 qs[32] } (ggml-common.h:187-214) -> arrays
+            tmp.resize(nbytes);
+            if (loader->read(loader->context, tmp.data(), nbytes) != nbytes) { WA_ERROR("%s: truncated tensor '%s'\n", __func__, name.c_str()); return false; }
+            const size_t nb = (size_t) nelements / 32, bsz = s.type == 6 ? 22 : 34, qsb = s.type == 6 ? 16 : 32;
+            uint8_t * qs = img.data() + s.off; uint32_t * qh = (uint32_t *) (img.data() + s.off2); float * qd = (float *) (img.data() + s.off3);
+            for (size_t b = 0; b < nb; ++b) {
+                const uint8_t * blk = tmp.data() + b * bsz;
+                wa_f16 dh; memcpy(&dh, blk, 2);
+                qd[b] = h2f_host(dh);
+                if (s.type == 6) { memcpy(&qh[b], blk + 2, 4); memcpy(qs + b * qsb, blk + 6, 16); }
+                else { qh[b] = 0; memcpy(qs + b * qsb, blk + 2, 32); }
+            }
+        } else if (s.kind == 0) {
             if (loader->read(loader->context, img.data() + s.off, nbytes) != nbytes) { WA_ERROR("%s: truncated tensor '%s'\n", __func__, name.c_str()); return false; }
         } else {
             tmp.resize(nbytes);
@@ -357,7 +399,11 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
     auto PF = [&](size_t o) { return (const float *) (base + o); };
     auto PH = [&](size_t o) { return (const wa_f16 *) (base + o); };
     auto LN = [&](ln_off o) { wa_ln r; r.w = PF(o.w); r.b = PF(o.b); return r; };
-    auto LIN = [&](lin_off o, int n_out, int n_in) { wa_lin r; r.w = PH(o.w); r.b = PF(o.b); r.s = o.s ? PF(o.s) : nullptr; r.n_out = n_out; r.n_in = n_in; return r; };
+    auto LIN = [&](lin_off o, int n_out, int n_in) {
+        wa_lin r; r.w = PH(o.w); r.b = PF(o.b); r.s = o.s ? PF(o.s) : nullptr; r.n_out = n_out; r.n_in = n_in;
+        if (o.qs) { r.w = nullptr; r.wtype = model.wtype; r.qs = base + o.qs; r.qh = (const uint32_t *) (base + o.qh); r.qd = PF(o.qd); }
+        return r;
+    };
 
     model.d_filters = PF(o_filters); model.d_hann = PF(o_hann); model.d_sincos = PF(o_sincos); model.d_gelu = PH(o_gelu);
     model.e_pe = PF(o_epe);
@@ -371,7 +417,8 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
         model.enc[i].qkv = LIN(eo[i].qkv, 3 * d, d);  model.enc[i].out = LIN(eo[i].out, d, d);
         model.enc[i].fc1 = LIN(eo[i].fc1, 4 * d, d);  model.enc[i].fc2 = LIN(eo[i].fc2, d, 4 * d);
     }
-    model.d_pe = PF(o_dpe); model.d_te = PH(o_dte); model.d_ln = LN(o_dln);
+    model.d_pe = PF(o_dpe); model.d_te = QT == 1 ? PH(o_dte) : nullptr; model.d_ln = LN(o_dln);
+    if (QT != 1) { lin_off t = o_teq; t.b = 0; model.te_q = LIN(t, hp.n_vocab, d); model.te_q.b = nullptr; }
     model.dec.resize(Ld);
     for (int i = 0; i < Ld; ++i) {
         auto & L = model.dec[i];
@@ -380,7 +427,7 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
         L.cross_q = LIN(dof[i].cq, d, d);  L.cross_out = LIN(dof[i].cout, d, d);
         L.fc1 = LIN(dof[i].fc1, 4 * d, d); L.fc2 = LIN(dof[i].fc2, d, 4 * d);
     }
-    model.cross_kv = LIN(lin_off{ o_ckv_w, o_ckv_b, o_ckv_s }, Ld * 2 * d, d);
+    { lin_off t = o_ckvq; t.w = o_ckv_w; t.b = o_ckv_b; t.s = o_ckv_s; model.cross_kv = LIN(t, Ld * 2 * d, d); }
 
     {   // per-layer pointer table of the one-launch decode step (wa_mega.hip)
         std::vector<wa_mega_layer> tab(Ld);
@@ -394,7 +441,7 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
             t.ln3_w = L.mlp_ln.w;   t.ln3_b = L.mlp_ln.b;   t.fc1_w = L.fc1.w; t.fc1_b = L.fc1.b;
             t.fc2_w = L.fc2.w;      t.fc2_b = L.fc2.b;
         }
-        if (Ld > 0) {
+        if (Ld > 0 && QT == 1) {      // (the one-launch decode step is built for F16 weights)
             if (!WA_HIP_OK(hipMalloc(&model.d_mega_layers, tab.size() * sizeof(wa_mega_layer)))) return false;
             if (!WA_HIP_OK(hipMemcpy(model.d_mega_layers, tab.data(), tab.size() * sizeof(wa_mega_layer), hipMemcpyHostToDevice))) return false;
         }
