@@ -424,4 +424,9 @@ def test_quantised_models_bit_exact(wrs, amd_lib, qt):
             except AssertionError as ex:
                 raise AssertionError("%s %s seed %d: %s" % (qt, tag, aseed, ex))
             st.free()
+    # config 5's calling pattern: sliding windows with a reduced audio context, single segment, carried prompt tokens
+    got = g.stream_run(wrs, amd_lib, ctx)
+    assert len(got) == len(gold["stream"])
+    for a, b in zip(got, gold["stream"]):
+        _same(a, b)
     ctx.free()

@@ -8,9 +8,11 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 n_past = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 flash = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
 lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
-ctx = W.WhisperContext.new_with_params(wsynth.model_path(name), W.WhisperContextParameters(lib, flash_attn=flash), lib=lib)
+mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)      # "small:q5_0" = the quantised file
+ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib, flash_attn=flash), lib=lib)
 st = ctx.create_state()
-st.pcm_to_mel(wsynth.synth_audio(480000, 0)); st.encode(0); st.encode(0)
+import time
+st.pcm_to_mel(wsynth.synth_audio(480000, 0)); st.encode(0); t0 = time.perf_counter(); st.encode(0); print("encode: %.2f ms" % (1e3 * (time.perf_counter() - t0)))
 lib.whisper_amd_decode_step_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
 ms = C.c_float()
 for _ in range(3):

@@ -24,6 +24,27 @@ FULL = {
 }
 
 
+def stream_run(Wm, lib, ctx, n_threads=None):
+    """BASELINE config 5's calling pattern (examples/stream/stream.cpp:311-335): full() on a sliding window (6 s every 3 s) with a
+    reduced audio context, single_segment, a token cap, no temperature fallback, and the previous window's tokens as prompt."""
+    pcm = wsynth.synth_audio(16000 * 15, 9)
+    st = ctx.create_state()
+    out, prompt = [], []
+    for it in range(4):
+        win = np.ascontiguousarray(pcm[it * 48000: it * 48000 + 96000])
+        kw = dict(best_of=1, temperature_inc=0.0, single_segment=True, max_tokens=32, audio_ctx=768, no_context=True)
+        if n_threads:
+            kw["n_threads"] = n_threads
+        if prompt:
+            kw["prompt_tokens"] = prompt
+        st.full(Wm.FullParams(lib, 0, **kw), win)
+        sg = segs(st)
+        out.append(sg)
+        prompt = [i for s_ in sg for i in s_["ids"]][-16:]
+    st.free()
+    return out
+
+
 def digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -62,6 +83,7 @@ if __name__ == "__main__":
                 st.full(W.FullParams(ref, kw.get("strategy", 0), n_threads=8, **kk), wsynth.synth_audio(480000, aseed))
                 g["full"]["%s_seed%d" % (tag, aseed)] = segs(st)
                 st.free()
+        g["stream"] = stream_run(W, ref, ctx, 8)
         gold[qt] = g
         ctx.free()
         print(qt, "done", {k: len(v) for k, v in g["full"].items()})
