@@ -162,52 +162,68 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
 }
 
 // The same pass for a quantised model (Q5_0 / Q8_0 weights, wa_quant.hip): every product quantises its F32 operand row to Q8_0
-// first, so LayerNorm, attention and GELU hand over F32.  Eager launches (no graph, no one-launch step).
+// first (fused into the LayerNorm launch where the operand is a LayerNorm output), so attention and GELU hand over F32.
 static void decode_launch_quant(whisper_context & ctx, whisper_state & st, int n_tokens, int n_kv, int kv_head, const int8_t * mask, int n_rows,
-                                const int32_t * h_rows, bool save_aheads) {
+                                const int32_t * h_rows, bool save_aheads, const int * dyn = nullptr) {
     const auto & m  = ctx.model;
     const auto & hp = m.hp;
     auto & kv = st.kv_self;
     const int n_vocab = hp.n_vocab, d = hp.n_text_state, H = hp.n_text_head;
     const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
     hipStream_t s = st.stream;
+    auto qmul = [&](wa_epi_mode mode, const wa_lin & L, int M, const wa_epi & e) {      // operand already in d_q8 / d_q8d
+        wa_launch_qgemm_exact(s, mode, st.d_q8, st.d_q8d, M, L.qs, L.qd, L.n_out, L.n_in, e);
+    };
     auto qlin = [&](wa_epi_mode mode, const float * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
         wa_launch_quantize_q8_0(s, A, lda, M, L.n_in, st.d_q8, st.d_q8d);
-        wa_launch_qgemm_exact(s, mode, st.d_q8, st.d_q8d, M, L.wtype, L.qs, L.qh, L.qd, L.n_out, L.n_in, e);
+        qmul(mode, L, M, e);
     };
-    wa_launch_dec_embed_q(s, st.d_tok, st.d_pos, n_tokens, d, m.te_q.wtype, m.te_q.qs, m.te_q.qh, m.te_q.qd, m.d_pe, st.d_dx);
+    auto ln_q = [&](const float * x, int rows, const wa_ln & ln) {
+        wa_launch_layernorm_exact(s, x, d, rows, d, ln.w, ln.b, hp.eps, nullptr, 0, nullptr, 0, st.d_q8, st.d_q8d);
+    };
+    wa_launch_dec_embed_q(s, st.d_tok, st.d_pos, n_tokens, d, m.te_q.qs, m.te_q.qd, m.d_pe, st.d_dx);
     const float KQscale = pow(float(64), -0.25);
     const size_t kv_layer = (size_t) kv.size * d, cross_layer = (size_t) H * st.cross_tpad * 64;
+    // second operand buffer (upper half of d_q8 / d_q8d) for the one product whose output is quantised by its own launch
+    int8_t * q8b = st.d_q8 + (size_t) st.q8_rows * 2 * d; float * q8bd = st.d_q8d + (size_t) st.q8_rows * 2 * d / 32;
     for (int il = 0; il < hp.n_text_layer; ++il) {
         const auto & L = m.dec[il];
-        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.attn_ln.w, L.attn_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
+        ln_q(st.d_dx, n_tokens, L.attn_ln);
         {
             wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
             e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
-            e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head;
-            qlin(WA_EPI_DEC_QKV, st.d_q32a, d, L.qkv, n_tokens, e);
+            e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head; e.dyn = dyn;
+            qmul(WA_EPI_DEC_QKV, L.qkv, n_tokens, e);
         }
         wa_launch_attn_exact(s, st.d_dq, d, kv.k + il * kv_layer, 64, d, kv.v + il * kv_layer, 64, d, H, n_tokens, n_kv, mask, 1.0f,
-                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr, nullptr, st.d_q32a);
-        { wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32a, d, L.out, n_tokens, e); }
-        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.cross_ln.w, L.cross_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
-        { wa_epi e; e.bias = L.cross_q.b; e.out = st.d_dq; e.ldo = d; qlin(WA_EPI_F16, st.d_q32a, d, L.cross_q, n_tokens, e); }
+                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr, dyn, nullptr, st.d_q8, st.d_q8d);
+        { wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qmul(WA_EPI_RESID, L.out, n_tokens, e); }
+        ln_q(st.d_dx, n_tokens, L.cross_ln);
+        { wa_epi e; e.bias = L.cross_q.b; e.out = st.d_dq; e.ldo = d; qmul(WA_EPI_F16, L.cross_q, n_tokens, e); }
         float * qk_out = nullptr;
         if (save_aheads && st.d_aheads_qk && il < (int) st.aheads_slot.size() && st.aheads_slot[il] >= 0)
             qk_out = st.d_aheads_qk + (size_t) st.aheads_slot[il] * n_tokens * H * T;
         wa_launch_attn_exact(s, st.d_dq, d, st.d_cross_k + il * cross_layer, (size_t) st.cross_tpad * 64, 64, st.d_cross_v + il * cross_layer,
                              (size_t) st.cross_tpad * 64, 64, H, n_tokens, T, nullptr, KQscale, st.d_att_partial, st.d_att_pleft, st.d_dao, d, qk_out,
-                             nullptr, st.d_q32a);
-        { wa_epi e; e.bias = L.cross_out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32a, d, L.cross_out, n_tokens, e); }
-        wa_launch_layernorm_exact(s, st.d_dx, d, n_tokens, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
-        { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_q32b; e.ldo = 4 * d; qlin(WA_EPI_GELU_F32, st.d_q32a, d, L.fc1, n_tokens, e); }
-        { wa_epi e; e.bias = L.fc2.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32b, 4 * d, L.fc2, n_tokens, e); }
+                             nullptr, nullptr, st.d_q8, st.d_q8d);
+        { wa_epi e; e.bias = L.cross_out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d; qmul(WA_EPI_RESID, L.cross_out, n_tokens, e); }
+        ln_q(st.d_dx, n_tokens, L.mlp_ln);
+        wa_epi e2; e2.bias = L.fc2.b; e2.out = st.d_dx; e2.ldo = d; e2.resid = st.d_dx; e2.ldr = d;
+        if (n_tokens == 1) {
+            wa_launch_qgemv_gelu_q8(s, st.d_q8, st.d_q8d, L.fc1.qs, L.fc1.qd, 4 * d, d, L.fc1.b, m.d_gelu, q8b, q8bd);
+            wa_launch_qgemm_exact(s, WA_EPI_RESID, q8b, q8bd, 1, L.fc2.qs, L.fc2.qd, d, 4 * d, e2);
+        } else {
+            { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_q32b; e.ldo = 4 * d; qmul(WA_EPI_GELU_F32, L.fc1, n_tokens, e); }
+            qlin(WA_EPI_RESID, st.d_q32b, 4 * d, L.fc2, n_tokens, e2);
+        }
     }
     if (n_rows) {       // final LayerNorm of the flagged rows (packed), then the logits product over the quantised token embedding
+        const int nb = d >> 5;
         for (int i = 0; i < n_rows; ++i)
-            wa_launch_layernorm_exact(s, st.d_dx + (size_t) h_rows[i] * d, d, 1, d, m.d_ln.w, m.d_ln.b, hp.eps, nullptr, 0, st.d_q32a + (size_t) i * d, d);
+            wa_launch_layernorm_exact(s, st.d_dx + (size_t) h_rows[i] * d, d, 1, d, m.d_ln.w, m.d_ln.b, hp.eps, nullptr, 0, nullptr, 0,
+                                      st.d_q8 + (size_t) i * d, st.d_q8d + (size_t) i * nb);
         wa_epi e; e.out = st.d_logits; e.ldo = n_vocab;
-        qlin(WA_EPI_F32, st.d_q32a, d, m.te_q, n_rows, e);
+        qmul(WA_EPI_F32, m.te_q, n_rows, e);
     }
 }
 
@@ -407,9 +423,8 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     if (n_rows) (void) hipMemcpyAsync(st.d_rows, h_rows, n_rows * sizeof(int32_t), hipMemcpyHostToDevice, s);
     (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
 
-    if (m.wtype != 1) {
-        decode_launch_quant(ctx, st, n_tokens, n_kv, kv_head, need_mask ? st.d_mask : nullptr, n_rows, h_rows, save_aheads);
-    } else if (st.graphs_enabled && steady) {
+    const int32_t row0 = 0;
+    if (st.graphs_enabled && steady) {
         const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx;
         if (st.dec_graph && (st.dec_graph_T != T || st.dec_graph_kv_size != kv.size || st.dec_graph_kv_k != kv.k)) {
             (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr;
@@ -420,7 +435,8 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
         if (!st.dec_graph) {
             hipGraph_t g = nullptr;
             if (WA_HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
-                decode_launch(ctx, st, 1, n_kv, kv_head, nullptr, 1, false, st.d_dyn);
+                if (m.wtype != 1) decode_launch_quant(ctx, st, 1, n_kv, kv_head, nullptr, 1, &row0, false, st.d_dyn);
+                else              decode_launch(ctx, st, 1, n_kv, kv_head, nullptr, 1, false, st.d_dyn);
                 if (WA_HIP_OK(hipStreamEndCapture(s, &g)) && g) {
                     if (!WA_HIP_OK(hipGraphInstantiate(&st.dec_graph, g, nullptr, nullptr, 0))) st.dec_graph = nullptr;
                     (void) hipGraphDestroy(g);
@@ -430,7 +446,10 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
             else { st.graphs_enabled = false; WA_WARN("%s: hipGraph capture failed, falling back to eager launches\n", __func__); }
         }
         if (st.dec_graph) { if (!WA_HIP_OK(hipGraphLaunch(st.dec_graph, s))) return false; }
+        else if (m.wtype != 1) decode_launch_quant(ctx, st, n_tokens, n_kv, kv_head, nullptr, n_rows, h_rows, save_aheads);
         else decode_launch(ctx, st, n_tokens, n_kv, kv_head, nullptr, n_rows, save_aheads);
+    } else if (m.wtype != 1) {
+        decode_launch_quant(ctx, st, n_tokens, n_kv, kv_head, need_mask ? st.d_mask : nullptr, n_rows, h_rows, save_aheads);
     } else {
         decode_launch(ctx, st, n_tokens, n_kv, kv_head, need_mask ? st.d_mask : nullptr, n_rows, save_aheads);
     }
@@ -490,17 +509,18 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     h[3] = n_past + 1; h[4] = n_past;
     (void) hipMemcpyAsync(st->d_dyn, h + 3, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s);
     hipGraphExec_t ge = nullptr;
-    if (st->graphs_enabled && ctx->model.wtype == 1) {
+    const int32_t row0 = 0;
+    if (st->graphs_enabled) {
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false, st->d_dyn);
+            if (ctx->model.wtype != 1) decode_launch_quant(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, &row0, false, st->d_dyn);
+            else                       decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false, st->d_dyn);
             if (hipStreamEndCapture(s, &g) == hipSuccess && g) { if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) ge = nullptr; (void) hipGraphDestroy(g); }
         }
     }
-    const int32_t row0 = 0;
     auto one = [&]() {
-        if (ctx->model.wtype != 1) decode_launch_quant(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, &row0, false);
-        else if (ge) (void) hipGraphLaunch(ge, s);
+        if (ge) (void) hipGraphLaunch(ge, s);
+        else if (ctx->model.wtype != 1) decode_launch_quant(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, &row0, false);
         else decode_launch(*ctx, *st, 1, n_past + 1, n_past, nullptr, 1, false);
     };
     one();      // warm-up

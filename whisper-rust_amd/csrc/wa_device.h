@@ -91,6 +91,19 @@ __device__ __forceinline__ float wa_gelu(float x, const wa_f16 * __restrict__ ta
     return h2f(table[f2h(x)]);
 }
 
+// quantize_row_q8_0 (ggml-cpu/arch/x86/quants.c, AVX2: d = max|x| / 127, q = rint(x * (127 / max|x|)), d kept as F16) of one 32-element
+// block whose element `el` = lane & 31 is held by each lane of a half-wave; output in the kernel layout of wa_quant.hip
+// (qs [row][el / 4][block][el % 4], qd [row][block]).  All 32 lanes of the half-wave must be active.
+__device__ __forceinline__ void wa_q8_store(float y, int row, int blk, int el, int nb, int8_t * __restrict__ qs, float * __restrict__ qd) {
+    float a = fabsf(y);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 32));
+    const float d = a / 127.f;
+    const float id = a != 0.0f ? 127.f / a : 0.0f;
+    qs[(((size_t) row * 8 + (el >> 2)) * nb + blk) * 4 + (el & 3)] = (int8_t) (int) rintf(y * id);      // to nearest, ties to even
+    if (el == 0) qd[(size_t) row * nb + blk] = h2f(f2h(d));       // the dot product reads the scale back from its F16 field
+}
+
 // =================================================================================================
 // GEMM epilogues (shared by the MFMA GEMM and the GEMV)
 // =================================================================================================

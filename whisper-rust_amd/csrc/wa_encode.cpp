@@ -101,6 +101,7 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
     if (ctx.model.wtype != 1) {
         if (!dev_alloc(st.d_q32a, (size_t) tpad * d) || !dev_alloc(st.d_q32b, (size_t) tpad * 4 * d) || !dev_alloc(st.d_q8, (size_t) tpad * 4 * d) ||
             !dev_alloc(st.d_q8d, (size_t) tpad * 4 * d / 32)) return false;
+        st.q8_rows = tpad;
     }
     if (!dev_alloc(st.d_im2col, std::max((size_t) 2 * T * 3 * hp.n_mels, (size_t) T * 3 * d) + 64)) return false;
     if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_stage_i32, (size_t) 4 * mpad * sizeof(int32_t)))) return false;
@@ -264,19 +265,23 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
     if (m.wtype != 1) {
         // Quantised model: every 2-D weight is Q5_0 / Q8_0 and the reference multiplies it with the Q8_0 form of the F32
         // activation row (wa_quant.hip).  Same sequence as below; the operands of the products stay F32 until they are quantised.
+        auto qmul = [&](wa_epi_mode mode, const wa_lin & L, int M, const wa_epi & e) {       // operand rows already in d_q8 / d_q8d
+            wa_launch_qgemm_exact(s, mode, st.d_q8, st.d_q8d, M, L.qs, L.qd, L.n_out, L.n_in, e);
+        };
         auto qlin = [&](wa_epi_mode mode, const float * A, int lda, const wa_lin & L, int M, const wa_epi & e) {
             wa_launch_quantize_q8_0(s, A, lda, M, L.n_in, st.d_q8, st.d_q8d);
-            wa_launch_qgemm_exact(s, mode, st.d_q8, st.d_q8d, M, L.wtype, L.qs, L.qh, L.qd, L.n_out, L.n_in, e);
+            qmul(mode, L, M, e);
         };
         for (int il = 0; il < hp.n_audio_layer; ++il) {
             const auto & L = m.enc[il];
-            wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
-            { wa_epi e; e.bias = L.qkv.b; e.out = st.d_ff; e.ldo = 3 * d; qlin(WA_EPI_F16, st.d_q32a, d, L.qkv, T, e); }
+            // (LayerNorm and attention quantise their F32 result rows themselves: wa_q8_store)
+            wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, nullptr, 0, nullptr, 0, st.d_q8, st.d_q8d);
+            { wa_epi e; e.bias = L.qkv.b; e.out = st.d_ff; e.ldo = 3 * d; qmul(WA_EPI_F16, L.qkv, T, e); }
             wa_launch_attn_exact(s, st.d_ff, 3 * d, st.d_ff + d, 64, 3 * d, st.d_ff + 2 * d, 64, 3 * d, H, T, T, nullptr, KQscale,
-                                 st.d_att_partial, st.d_att_pleft, st.d_ao, d, nullptr, nullptr, st.d_q32a);
-            { wa_epi e; e.bias = L.out.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32a, d, L.out, T, e); }
-            wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, nullptr, 0, st.d_q32a, d);
-            { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_q32b; e.ldo = 4 * d; qlin(WA_EPI_GELU_F32, st.d_q32a, d, L.fc1, T, e); }
+                                 st.d_att_partial, st.d_att_pleft, st.d_ao, d, nullptr, nullptr, nullptr, st.d_q8, st.d_q8d);
+            { wa_epi e; e.bias = L.out.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d; qmul(WA_EPI_RESID, L.out, T, e); }
+            wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, nullptr, 0, nullptr, 0, st.d_q8, st.d_q8d);
+            { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_q32b; e.ldo = 4 * d; qmul(WA_EPI_GELU_F32, L.fc1, T, e); }
             { wa_epi e; e.bias = L.fc2.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d; qlin(WA_EPI_RESID, st.d_q32b, 4 * d, L.fc2, T, e); }
         }
         wa_launch_layernorm_exact(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, nullptr, 0, st.d_embd_enc, d);

@@ -122,7 +122,9 @@ __device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d
                                             float & mean, float & scale) {
     double s = 0.0, a = 0.0;
 #pragma unroll
-    for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? xr[i] : 0.0f; if (i < d) lrow[i] = xv[k]; }
+    for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k; xv[k] = xr[i < d ? i : d - 1]; }      // unconditional loads: all in flight together
+#pragma unroll
+    for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k; if (i < d) lrow[i] = xv[k]; else xv[k] = 0.0f; }
 #pragma unroll
     for (int k = 0; k < LN_NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }    // padding adds exact zeros
     s = wave_sum_d(s); a = wave_sum_d(a);
@@ -146,13 +148,15 @@ __device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d
 
 __global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
                                                          const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
-                                                         float * __restrict__ out32, int ld32) {
+                                                         float * __restrict__ out32, int ld32, int8_t * __restrict__ qs, float * __restrict__ qd) {
     __shared__ __attribute__((aligned(16))) float lrows[4][64 * LN_NPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const float * xr = x + (size_t) row * ldx;
-    float xv[LN_NPL], mean, scale;
+    float xv[LN_NPL], gw[LN_NPL], gb[LN_NPL], mean, scale;
+#pragma unroll
+    for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; gw[k] = w[ic]; gb[k] = b[ic]; }
     wa_ln_stats(xr, d, eps, lane, lrows[wave], xv, mean, scale);
 #pragma unroll
     for (int k = 0; k < LN_NPL; ++k) {
@@ -160,16 +164,17 @@ __global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restric
         if (i < d) {
             float y = xv[k] - mean;
             y = y * scale;
-            y = y * w[i];
-            y = y + b[i];
+            y = y * gw[k];
+            y = y + gb[k];
             if (out16) out16[(size_t) row * ld16 + i] = f2h(y);
             if (out32) out32[(size_t) row * ld32 + i] = y;
+            if (qs) wa_q8_store(y, row, i >> 5, i & 31, d >> 5, qs, qd);      // d % 32 == 0: a half-wave holds one block
         }
     }
 }
 void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
-                               wa_f16 * out16, int ld16, float * out32, int ld32) {
-    hipLaunchKernelGGL(k_layernorm_exact, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32);
+                               wa_f16 * out16, int ld16, float * out32, int ld32, int8_t * qs, float * qd) {
+    hipLaunchKernelGGL(k_layernorm_exact, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32, qs, qd);
 }
 
 // =================================================================================================
@@ -198,8 +203,9 @@ __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr
     for (int k = 0; k < GEMV_LN_NPL; ++k) {
         const int i = tid + GEMV_THREADS * k;
         const bool ok = i < K;
-        xv[k] = ok ? xr[i] : 0.0f; gw[k] = ok ? ln.w[i] : 0.0f; gb[k] = ok ? ln.b[i] : 0.0f;
-        if (ok) lrow[i] = xv[k];
+        const int ic = ok ? i : K - 1;                       // unconditional loads: all in flight together
+        xv[k] = xr[ic]; gw[k] = ln.w[ic]; gb[k] = ln.b[ic];
+        if (ok) lrow[i] = xv[k]; else { xv[k] = 0.0f; gw[k] = 0.0f; gb[k] = 0.0f; }
     }
     double s = 0.0, a = 0.0;
 #pragma unroll
@@ -411,7 +417,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
                                                             int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
                                                             int n_kv_arg, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
                                                             wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out,
-                                                            const int * __restrict__ dyn, float * __restrict__ out32) {
+                                                            const int * __restrict__ dyn, float * __restrict__ out32, int8_t * __restrict__ q8,
+                                                            float * __restrict__ q8d) {
     constexpr int NW = ATT_THREADS / 64;
     const int n_kv = dyn ? dyn[0] : n_kv_arg;
     __shared__ float sc[ATT_MAXKV];
@@ -561,7 +568,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
             }
 #pragma unroll
             for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
-            if (out32) out32[(size_t) j * ldo + h * 64 + tid] = (float) sumf;
+            if (q8) wa_q8_store((float) sumf, j, 2 * h + (tid >> 5), tid & 31, ldo >> 5, q8, q8d);       // F32 hand-over, quantised (wa_quant.hip)
+            else if (out32) out32[(size_t) j * ldo + h * 64 + tid] = (float) sumf;
             else out[(size_t) j * ldo + h * 64 + tid] = f2h((float) sumf);
         }
     } else {
@@ -574,7 +582,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
 
 __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ partial, const wa_f16 * __restrict__ p_left,
                                                      const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride, int n_kv_arg,
-                                                     wa_f16 * __restrict__ out, int ldo, const int * __restrict__ dyn, float * __restrict__ out32) {
+                                                     wa_f16 * __restrict__ out, int ldo, const int * __restrict__ dyn, float * __restrict__ out32,
+                                                     int8_t * __restrict__ q8, float * __restrict__ q8d) {
     const int j = blockIdx.x, h = blockIdx.y, n_head = gridDim.y, dh = threadIdx.x;
     const int n_kv = dyn ? dyn[0] : n_kv_arg;
     const size_t pb = ((size_t) j * n_head + h) * 32;
@@ -592,23 +601,25 @@ __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ 
     }
 #pragma unroll
     for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
-    if (out32) out32[(size_t) j * ldo + h * 64 + dh] = (float) sumf;
+    if (q8) wa_q8_store((float) sumf, j, 2 * h + (dh >> 5), dh & 31, ldo >> 5, q8, q8d);
+    else if (out32) out32[(size_t) j * ldo + h * 64 + dh] = (float) sumf;
     else out[(size_t) j * ldo + h * 64 + dh] = f2h((float) sumf);
 }
 
 void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
-                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn, float * out32) {
+                          float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn, float * out32,
+                          int8_t * q8, float * q8d) {
     // few (token, head) pairs and a long key range (decode cross-attention): spread the 32 partial-sum chains over 4 blocks
     // per pair and finish in k_attn_combine; otherwise one block per pair finishes in LDS (encoder, prompt, self-attention)
     const bool split = (long) n_tokens * n_head < 512 && n_kv > 512;
     if (!split) {
         hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32, q8, q8d);
     } else {
         hipLaunchKernelGGL((k_attn_exact<4>), dim3(n_head * 4, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32, q8, q8d);
         hipLaunchKernelGGL(k_attn_combine, dim3(n_tokens, n_head), dim3(64), 0, s, partial, p_left, vbase, v_head_stride, v_row_stride, n_kv,
-                           out, ldo, dyn, out32);
+                           out, ldo, dyn, out32, q8, q8d);
     }
 }

@@ -62,11 +62,11 @@ typedef uint16_t wa_f16;  // raw IEEE half bits on the host side
 
 struct wa_ln  { const float * w = nullptr; const float * b = nullptr; };
 // A linear layer.  F16 weights: w [n_out][n_in].  Quantised weights (ggml block formats, ggml-common.h:187-214; wtype = ggml type
-// 6 Q5_0 / 8 Q8_0) are kept structure-of-arrays per 32-element block: qs [n_out][n_in/32][16 or 32] quant bytes,
-// qh [n_out][n_in/32] fifth bits (Q5_0), qd [n_out][n_in/32] block scales widened from F16 to F32 (exact).
+// 6 Q5_0 / 8 Q8_0): qs = the quants as signed bytes [n_out][8][n_in/32][4] (element 4l + e of block b at [row][l][b][e]; Q5_0's
+// 5-bit values expanded at load), qd [n_out][n_in/32] the block scales widened from F16 to F32 (exact).
 struct wa_lin {
     const wa_f16 * w = nullptr; const float * b = nullptr; const float * s = nullptr; int n_out = 0, n_in = 0;
-    int wtype = 1; const uint8_t * qs = nullptr; const uint32_t * qh = nullptr; const float * qd = nullptr;
+    int wtype = 1; const int8_t * qs = nullptr; const float * qd = nullptr;
 };
 
 struct wa_enc_layer {
@@ -232,7 +232,8 @@ struct whisper_state {
     // quantised models (wa_quant.hip): F32 operands of the quantised products and their Q8_0 form (shared by encoder and decoder)
     float  * d_q32a = nullptr;      // [tpad][d]   LayerNorm / attention output
     float  * d_q32b = nullptr;      // [tpad][4d]  GELU(fc1)
-    int8_t * d_q8   = nullptr;      // [tpad][4d]
+    int8_t * d_q8   = nullptr;      // [tpad][4d]  Q8_0 operand rows (q8_rows = tpad)
+    int      q8_rows = 0;
     float  * d_q8d  = nullptr;      // [tpad][4d / 32]
 
     // hipGraph of the single-token decoder pass (launch-bound inner loop); parameters that change per token live in d_dyn

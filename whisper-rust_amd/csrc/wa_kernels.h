@@ -92,20 +92,24 @@ void wa_launch_ln_gemv_exact(hipStream_t stream, wa_epi_mode mode, const float *
                              const float * ln_b, float eps, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e);
 void wa_launch_im2col3(hipStream_t stream, const wa_f16 * src, int src_ld, int row0, int stride, int IC, int OL, wa_f16 * dst, int dst_ld);
 void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
-                               wa_f16 * out16, int ld16, float * out32, int ld32);
+                               wa_f16 * out16, int ld16, float * out32, int ld32, int8_t * qs = nullptr, float * qd = nullptr);
 // q [n_tokens][ldq] f16; K row c of head h at kbase + h*k_head_stride + c*k_row_stride (64 halfs), V likewise.
 // partial: f32 [n_tokens][n_head][32][64], p_left: f16 [n_tokens][n_head][32] (used when n_tokens*n_head < 512).
 void wa_launch_attn_exact(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
                           float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn_n_kv = nullptr,
-                          float * out32 = nullptr /* when set: the result in F32 [n_tokens][ldo] instead of F16 (quantised models) */);
+                          float * out32 = nullptr /* when set: the result in F32 [n_tokens][ldo] instead of F16 (quantised models) */,
+                          int8_t * q8 = nullptr, float * q8d = nullptr /* when set: the F32 result as Q8_0 rows in the layout of wa_launch_quantize_q8_0 */);
 
 // ---- quantised weights (wa_quant.hip): ggml's Q5_0 / Q8_0 x Q8_0 products in the reference's AVX2 order ----
-// quantize_row_q8_0 (arch/x86/quants.c): x f32 [rows][ldx] -> qs int8 [rows][K], qd f32 [rows][K/32] (block scale, rounded through F16)
+// quantize_row_q8_0 (arch/x86/quants.c): x f32 [rows][ldx] -> qs int8 [rows][8][K/32][4] (kernel layout), qd f32 [rows][K/32] (block scale, rounded through F16)
 void wa_launch_quantize_q8_0(hipStream_t stream, const float * x, int ldx, int rows, int K, int8_t * qs, float * qd);
-// C[M][N] = xq . Wq^T, ggml_vec_dot_q5_0_q8_0 / q8_0_q8_0 order; wtype 6 (Q5_0) or 8 (Q8_0); any M
-void wa_launch_qgemm_exact(hipStream_t stream, wa_epi_mode mode, const int8_t * xq, const float * xd, int M, int wtype, const uint8_t * wqs,
-                           const uint32_t * wqh, const float * wqd, int N, int K, const wa_epi & e);
+// C[M][N] = xq . Wq^T, ggml_vec_dot_q5_0_q8_0 / q8_0_q8_0 order; wq int8 [N][8][K/32][4], wd f32 [N][K/32] (wa_internal.h: wa_lin); any M
+void wa_launch_qgemm_exact(hipStream_t stream, wa_epi_mode mode, const int8_t * xq, const float * xd, int M, const int8_t * wq, const float * wd, int N, int K,
+                           const wa_epi & e);
+// M == 1: GELU(x Wq^T + bias) quantised to Q8_0 straight away (the operand of the second MLP product); N % 32 == 0
+void wa_launch_qgemv_gelu_q8(hipStream_t stream, const int8_t * xq, const float * xd, const int8_t * wq, const float * wd, int N, int K, const float * bias,
+                             const wa_f16 * gelu, int8_t * oq, float * oqd);
 // token embedding rows of a quantised matrix (dequantize_row_q5_0 / q8_0) + positional embedding
-void wa_launch_dec_embed_q(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d, int wtype, const uint8_t * wqs,
-                           const uint32_t * wqh, const float * wqd, const float * pe, float * x);
+void wa_launch_dec_embed_q(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d, const int8_t * wq, const float * wd,
+                           const float * pe, float * x);

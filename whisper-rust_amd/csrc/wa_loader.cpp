@@ -32,7 +32,7 @@ inline float gelu_f32(float x) {
 
 struct slot {             // where a named tensor goes
     int    kind;          // 0 raw copy, 1 conv weight re-order ([oc][ic][3] -> [oc][3][ic], row stride ld),
-                          // 2 quantised blocks -> structure of arrays (off = quant bytes, off2 = fifth bits, off3 = scales)
+                          // 2 quantised blocks -> kernel layout (off = signed quant bytes [row][8][block][4], off3 = scales [row][block])
     size_t off;           // byte offset in the arena
     int    type;          // expected ggml type: 0 f32, 1 f16
     int64_t ne[3];        // expected ne[] (fastest first)
@@ -190,14 +190,14 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
 
     struct lin_off { size_t w, b, s; size_t qs = 0, qh = 0, qd = 0; };
     const int QT = model.wtype;                                  // 1, 6 or 8
-    const size_t QSB = QT == 6 ? 16 : 32;                        // quant bytes per 32-element block
-    auto take_q = [&](lin_off & o, size_t n_out, size_t n_in) {  // SoA storage of a quantised [n_out][n_in] matrix
-        const size_t nb = n_out * (n_in / 32);
-        o.qs = ab.take(nb * QSB); o.qh = ab.take(nb * 4); o.qd = ab.take(nb * 4);
+    // Kernel layout of a quantised [n_out][n_in] matrix: the quants as signed bytes (Q5_0's 5-bit values are expanded once, here),
+    // ordered [row][lane l = 0..7][block][4] - lane l of a row's 8-lane group owns elements 4l..4l+3 of EVERY block, so its bytes
+    // are contiguous over the blocks (16-byte loads cover four blocks) - and the block scales [row][block] as F32.
+    auto take_q = [&](lin_off & o, size_t n_out, size_t n_in) {
+        o.qs = ab.take(n_out * n_in); o.qh = 0; o.qd = ab.take(n_out * (n_in / 32) * 4);
     };
     auto add_q = [&](const std::string & name, const lin_off & o, size_t row0, int64_t n_in, int64_t n_rows) {
-        const size_t b0 = row0 * (size_t) (n_in / 32);
-        slot s; s.kind = 2; s.off = o.qs + b0 * QSB; s.off2 = o.qh + b0 * 4; s.off3 = o.qd + b0 * 4; s.type = QT;
+        slot s; s.kind = 2; s.off = o.qs + row0 * (size_t) n_in; s.off2 = 0; s.off3 = o.qd + row0 * (size_t) (n_in / 32) * 4; s.type = QT;
         s.ne[0] = n_in; s.ne[1] = n_rows; s.ne[2] = 1; s.ld = 0;
         slots[name] = s;
     };
@@ -351,15 +351,23 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
         if (s.kind == 2) {        // block_q5_0 { f16 d; u32 qh; u8 qs[16] } / block_q8_0 { f16 d; i8 qs[32] } (ggml-common.h:187-214) -> arrays
             tmp.resize(nbytes);
             if (loader->read(loader->context, tmp.data(), nbytes) != nbytes) { WA_ERROR("%s: truncated tensor '%s'\n", __func__, name.c_str()); return false; }
-            const size_t nb = (size_t) nelements / 32, bsz = s.type == 6 ? 22 : 34, qsb = s.type == 6 ? 16 : 32;
-            uint8_t * qs = img.data() + s.off; uint32_t * qh = (uint32_t *) (img.data() + s.off2); float * qd = (float *) (img.data() + s.off3);
-            for (size_t b = 0; b < nb; ++b) {
-                const uint8_t * blk = tmp.data() + b * bsz;
-                wa_f16 dh; memcpy(&dh, blk, 2);
-                qd[b] = h2f_host(dh);
-                if (s.type == 6) { memcpy(&qh[b], blk + 2, 4); memcpy(qs + b * qsb, blk + 6, 16); }
-                else { qh[b] = 0; memcpy(qs + b * qsb, blk + 2, 32); }
-            }
+            const size_t bsz = s.type == 6 ? 22 : 34, nbr = (size_t) s.ne[0] / 32, rows = (size_t) s.ne[1];
+            int8_t * qs = (int8_t *) (img.data() + s.off); float * qd = (float *) (img.data() + s.off3);
+            for (size_t r = 0; r < rows; ++r)
+                for (size_t b = 0; b < nbr; ++b) {
+                    const uint8_t * blk = tmp.data() + (r * nbr + b) * bsz;
+                    wa_f16 dh; memcpy(&dh, blk, 2);
+                    qd[r * nbr + b] = h2f_host(dh);
+                    int8_t v[32];
+                    if (s.type == 6) {      // element j < 16: low nibble of qs[j], j + 16: high nibble; bit e of qh: fifth bit; value - 16
+                        uint32_t qh; memcpy(&qh, blk + 2, 4);
+                        for (int j = 0; j < 16; ++j) {
+                            v[j]      = (int8_t) ((int) ((blk[6 + j] & 0x0f) | (((qh >> j) & 1u) << 4)) - 16);
+                            v[j + 16] = (int8_t) ((int) ((blk[6 + j] >> 4)   | (((qh >> (j + 16)) & 1u) << 4)) - 16);
+                        }
+                    } else memcpy(v, blk + 2, 32);
+                    for (int l = 0; l < 8; ++l) memcpy(qs + ((r * 8 + l) * nbr + b) * 4, v + 4 * l, 4);
+                }
         } else if (s.kind == 0) {
             if (loader->read(loader->context, img.data() + s.off, nbytes) != nbytes) { WA_ERROR("%s: truncated tensor '%s'\n", __func__, name.c_str()); return false; }
         } else {
@@ -401,7 +409,7 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
     auto LN = [&](ln_off o) { wa_ln r; r.w = PF(o.w); r.b = PF(o.b); return r; };
     auto LIN = [&](lin_off o, int n_out, int n_in) {
         wa_lin r; r.w = PH(o.w); r.b = PF(o.b); r.s = o.s ? PF(o.s) : nullptr; r.n_out = n_out; r.n_in = n_in;
-        if (o.qs) { r.w = nullptr; r.wtype = model.wtype; r.qs = base + o.qs; r.qh = (const uint32_t *) (base + o.qh); r.qd = PF(o.qd); }
+        if (o.qs) { r.w = nullptr; r.wtype = model.wtype; r.qs = (const int8_t *) (base + o.qs); r.qd = PF(o.qd); }
         return r;
     };
 

@@ -7,11 +7,13 @@
 // (ggml_vec_dot_q5_0_q8_0 / ggml_vec_dot_q8_0_q8_0, same file; the integer sums are exact: |w| <= 16 or 127, |x| <= 127).
 // Here: 8 lanes per output row, lane l owns elements 4l..4l+3 of every 32-element block (one v_dot4_i32_i8 per block and
 // token), the three DPP exchanges reproduce hsum_float_8.  Up to 8 activation rows share one pass over the weights.
+// The weights are stored for this access pattern at load (wa_loader.cpp: signed bytes, [row][lane][block][4]).
 // Bit-identical to the reference engine on the Q5_0 / Q8_0 goldens (tests/test_parity_gpu.py).
 #include "wa_device.h"
 
 // -------------------------------------------------------------------------------------------------
-// quantize_row_q8_0: one 32-lane half-wave per block
+// quantize_row_q8_0: one 32-lane half-wave per block.  The quants are written in the kernel layout of the weights
+// ([row][l = 0..7][block][4], wa_internal.h: wa_lin): lane l of a dot product reads four blocks with one 16-byte load.
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_quantize_q8_0(const float * __restrict__ x, int ldx, int rows, int K, int8_t * __restrict__ qs,
                                                        float * __restrict__ qd) {
@@ -21,43 +23,33 @@ __global__ __launch_bounds__(256) void k_quantize_q8_0(const float * __restrict_
     const int l = (int) (g & 31);
     if (gb >= (long) rows * nb) return;
     const int row = (int) (gb / nb), b = (int) (gb - (long) row * nb);
-    const float v = x[(size_t) row * ldx + b * 32 + l];
-    float a = fabsf(v);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 32));
-    const float d = a / 127.f;
-    const float id = a != 0.0f ? 127.f / a : 0.0f;
-    const float r = rintf(v * id);                          // _mm256_round_ps(_MM_ROUND_NEAREST): to nearest, ties to even
-    qs[(size_t) row * K + b * 32 + l] = (int8_t) (int) r;
-    if (l == 0) qd[(size_t) row * nb + b] = h2f(f2h(d));   // the dot product reads the scale back from its F16 field
+    wa_q8_store(x[(size_t) row * ldx + b * 32 + l], row, b, l, nb, qs, qd);
 }
 void wa_launch_quantize_q8_0(hipStream_t stream, const float * x, int ldx, int rows, int K, int8_t * qs, float * qd) {
     const long n = (long) rows * K;
     hipLaunchKernelGGL(k_quantize_q8_0, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, x, ldx, rows, K, qs, qd);
 }
 
-// -------------------------------------------------------------------------------------------------
-// elements 4l..4l+3 of a weight block as four signed bytes
-// -------------------------------------------------------------------------------------------------
-template <int QT>
-__device__ __forceinline__ int wa_q_quad(const uint8_t * __restrict__ wqs, const uint32_t * __restrict__ wqh, size_t blk, int l) {
-    if (QT == 8) return *(const int *) (wqs + blk * 32 + 4 * l);
-    // Q5_0 (ggml-common.h:187-193): element j < 16 = low nibble of qs[j], element j + 16 = high nibble; bit e of qh = fifth bit of element e;
-    // value = (nibble | bit << 4) - 16, i.e. nibble if the bit is set, nibble | 0xF0 (as a signed byte) if not
-    const uint32_t q = *(const uint32_t *) (wqs + blk * 16 + 4 * (l & 3));
-    const uint32_t nib = (l < 4 ? q : q >> 4) & 0x0f0f0f0fu;
-    const uint32_t nb = ~(wqh[blk] >> (4 * l)) & 0xfu;                                       // bits NOT set, elements 4l..4l+3
-    const uint32_t spread = (nb & 1u) | ((nb & 2u) << 7) | ((nb & 4u) << 14) | ((nb & 8u) << 21);
-    return (int) (nib | spread * 0xf0u);
+typedef int   wq_i4 __attribute__((ext_vector_type(4)));
+typedef float wq_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wq_hsum8(float v) {
+    v = v + dpp_f32<0x104>(v);          // row_shl:4  acc[l] + acc[l+4]
+    v = v + dpp_f32<0x102>(v);          // row_shl:2  (a0+a4)+(a2+a6) | (a1+a5)+(a3+a7)
+    v = v + dpp_f32<0x101>(v);          // row_shl:1  the two halves
+    return v;
 }
+#define WQ_BLOCK(acc, w, dw, x, dx) acc = fmaf((dw) * (dx), (float) __builtin_amdgcn_sdot4((w), (x), 0, false), acc)
+#define WQ_STEP4(acc, W, DW, X, DX) do { WQ_BLOCK(acc, (W).x, (DW).x, (X).x, (DX).x); WQ_BLOCK(acc, (W).y, (DW).y, (X).y, (DX).y); \
+                                         WQ_BLOCK(acc, (W).z, (DW).z, (X).z, (DX).z); WQ_BLOCK(acc, (W).w, (DW).w, (X).w, (DX).w); } while (0)
 
 // -------------------------------------------------------------------------------------------------
-// C[M][N] = xq Wq^T; grid = (ceil(N / 32), ceil(M / 8)); 256 threads = 32 output rows x 8 lanes
+// C[M][N] = xq Wq^T, M > 1; grid = (ceil(N / 32), ceil(M / 8)); 256 threads = 32 output rows x 8 lanes; the 8 activation rows in LDS
 // -------------------------------------------------------------------------------------------------
-template <int QT, int EPI>
-__global__ __launch_bounds__(256) void k_qgemm_exact(const int8_t * __restrict__ xq, const float * __restrict__ xd, int M, const uint8_t * __restrict__ wqs,
-                                                     const uint32_t * __restrict__ wqh, const float * __restrict__ wqd, int N, int K, wa_epi e) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // xs int8 [8][K] | xds f32 [8][K/32]
+template <int EPI>
+__global__ __launch_bounds__(256) void k_qgemm_exact(const int8_t * __restrict__ xq, const float * __restrict__ xd, int M, const int8_t * __restrict__ wq,
+                                                     const float * __restrict__ wd, int N, int K, wa_epi e) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // xs int8 [8][K] (kernel layout) | xds f32 [8][K/32]
     const int nb = K >> 5;
     int8_t * xs = (int8_t *) smem;
     float * xds = (float *) (smem + (size_t) 8 * K);
@@ -79,68 +71,131 @@ __global__ __launch_bounds__(256) void k_qgemm_exact(const int8_t * __restrict__
     wa_epi_pre pre[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) if (l == 0 && m < mt) pre[m] = epi_preload<EPI>(e, m0 + m, nn);
-#pragma unroll 4
-    for (int b = 0; b < nb; ++b) {
-        const size_t blk = (size_t) nn * nb + b;
-        const int w4 = wa_q_quad<QT>(wqs, wqh, blk, l);
-        const float dw = wqd[blk];
+    const int * wl = (const int *) wq + ((size_t) nn * 8 + l) * nb;            // this lane's quads, block after block
+    const float * dl = wd + (size_t) nn * nb;
+    const int * xl = (const int *) xs + (size_t) l * nb;
+    if ((nb & 3) == 0) {
+        wq_i4 wn = *(const wq_i4 *) wl; wq_f4 dn = *(const wq_f4 *) dl;
+        for (int b = 0; b < nb; b += 4) {
+            const wq_i4 w = wn; const wq_f4 dw = dn;
+            const int bn = min(b + 4, nb - 4);
+            wn = *(const wq_i4 *) (wl + bn); dn = *(const wq_f4 *) (dl + bn);
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int x4 = *(const int *) (xs + (size_t) m * K + b * 32 + 4 * l);
-            const int isum = __builtin_amdgcn_sdot4(w4, x4, 0, false);
-            acc[m] = fmaf(dw * xds[m * nb + b], (float) isum, acc[m]);
+            for (int m = 0; m < 8; ++m) {
+                const wq_i4 x = *(const wq_i4 *) (xl + (size_t) m * (K >> 2) + b);
+                const wq_f4 dx = *(const wq_f4 *) (xds + m * nb + b);
+                WQ_STEP4(acc[m], w, dw, x, dx);
+            }
+        }
+    } else {
+        for (int b = 0; b < nb; ++b) {
+            const int w = wl[b]; const float dw = dl[b];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) WQ_BLOCK(acc[m], w, dw, xl[(size_t) m * (K >> 2) + b], xds[m * nb + b]);
         }
     }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        float v = acc[m];
-        v = v + dpp_f32<0x104>(v);          // row_shl:4  acc[l] + acc[l+4]
-        v = v + dpp_f32<0x102>(v);          // row_shl:2  (a0+a4)+(a2+a6) | (a1+a5)+(a3+a7)
-        v = v + dpp_f32<0x101>(v);          // row_shl:1  the two halves
+        const float v = wq_hsum8(acc[m]);
         if (l == 0 && n < N && m < mt) epi_apply<EPI>(e, m0 + m, n, v, pre[m]);
     }
 }
 
-template <int QT>
-static void qgemm_dispatch(hipStream_t s, wa_epi_mode mode, const int8_t * xq, const float * xd, int M, const uint8_t * wqs, const uint32_t * wqh,
-                           const float * wqd, int N, int K, const wa_epi & e) {
+// -------------------------------------------------------------------------------------------------
+// M == 1 (the decode step): grid = ceil(N / 8) single-wave workgroups, 8 output rows x 8 lanes each; no LDS, the activation row is
+// read from L2 with the same 16-byte pattern as the weights; 16 blocks (4 loads of each kind) in flight ahead of the arithmetic
+// -------------------------------------------------------------------------------------------------
+// one output row per 8 lanes: the row's dot product with the activation row (valid in lane l == 0 of the group)
+__device__ __forceinline__ float wq_row_dot(const int8_t * __restrict__ xq, const float * __restrict__ xd, const int8_t * __restrict__ wq,
+                                            const float * __restrict__ wd, int nn, int nb, int l) {
+    const int * wl = (const int *) wq + ((size_t) nn * 8 + l) * nb;
+    const float * dl = wd + (size_t) nn * nb;
+    const int * xl = (const int *) xq + (size_t) l * nb;
+    float acc = 0.0f;
+    if ((nb & 3) == 0) {
+        wq_i4 wn[4], xn[4]; wq_f4 dn[4], en[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int bj = min(4 * j, nb - 4);
+            wn[j] = *(const wq_i4 *) (wl + bj); dn[j] = *(const wq_f4 *) (dl + bj); xn[j] = *(const wq_i4 *) (xl + bj); en[j] = *(const wq_f4 *) (xd + bj);
+        }
+        for (int b = 0; b < nb; b += 16) {
+            wq_i4 w[4], x[4]; wq_f4 dw[4], dx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = wn[j]; x[j] = xn[j]; dw[j] = dn[j]; dx[j] = en[j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bj = min(b + 16 + 4 * j, nb - 4);
+                wn[j] = *(const wq_i4 *) (wl + bj); dn[j] = *(const wq_f4 *) (dl + bj); xn[j] = *(const wq_i4 *) (xl + bj); en[j] = *(const wq_f4 *) (xd + bj);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (b + 4 * j < nb) WQ_STEP4(acc, w[j], dw[j], x[j], dx[j]);
+        }
+    } else {
+        for (int b = 0; b < nb; ++b) WQ_BLOCK(acc, wl[b], dl[b], xl[b], xd[b]);
+    }
+    return wq_hsum8(acc);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(64) void k_qgemv_exact(const int8_t * __restrict__ xq, const float * __restrict__ xd, const int8_t * __restrict__ wq,
+                                                    const float * __restrict__ wd, int N, int K, wa_epi e) {
+    const int tid = threadIdx.x, l = tid & 7;
+    const int n = blockIdx.x * 8 + (tid >> 3);
+    const int nn = n < N ? n : N - 1;
+    wa_epi_pre pre;
+    if (l == 0) pre = epi_preload<EPI>(e, 0, nn);
+    const float v = wq_row_dot(xq, xd, wq, wd, nn, K >> 5, l);
+    if (l == 0 && n < N) epi_apply<EPI>(e, 0, n, v, pre);
+}
+
+// the first MLP product of the decode step: 4 waves = 32 output rows = one Q8_0 block of the GELU output (N % 32 == 0)
+__global__ __launch_bounds__(256) void k_qgemv_gelu_q8(const int8_t * __restrict__ xq, const float * __restrict__ xd, const int8_t * __restrict__ wq,
+                                                       const float * __restrict__ wd, int N, int K, const float * __restrict__ bias,
+                                                       const wa_f16 * __restrict__ gelu, int8_t * __restrict__ oq, float * __restrict__ oqd) {
+    __shared__ float g[32];
+    const int tid = threadIdx.x, l = tid & 7;
+    const int n = blockIdx.x * 32 + (tid >> 3);
+    const float bn = l == 0 ? bias[n] : 0.0f;
+    const float v = wq_row_dot(xq, xd, wq, wd, n, K >> 5, l);
+    if (l == 0) g[tid >> 3] = wa_gelu(v + bn, gelu);
+    __syncthreads();
+    if (tid < 32) wa_q8_store(g[tid], 0, blockIdx.x, tid, N >> 5, oq, oqd);
+}
+void wa_launch_qgemv_gelu_q8(hipStream_t s, const int8_t * xq, const float * xd, const int8_t * wq, const float * wd, int N, int K, const float * bias,
+                             const wa_f16 * gelu, int8_t * oq, float * oqd) {
+    hipLaunchKernelGGL(k_qgemv_gelu_q8, dim3(N / 32), dim3(256), 0, s, xq, xd, wq, wd, N, K, bias, gelu, oq, oqd);
+}
+
+void wa_launch_qgemm_exact(hipStream_t s, wa_epi_mode mode, const int8_t * xq, const float * xd, int M, const int8_t * wq, const float * wd, int N, int K,
+                           const wa_epi & e) {
     const dim3 grid((N + 31) / 32, (M + 7) / 8);
     const size_t lds = (size_t) 8 * K + (size_t) 8 * (K >> 5) * sizeof(float);
 #define WA_CASE(E) case E: { \
-        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_qgemm_exact<QT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL((k_qgemm_exact<QT, E>), grid, dim3(256), lds, s, xq, xd, M, wqs, wqh, wqd, N, K, e); } break;
+        if (M == 1) { hipLaunchKernelGGL((k_qgemv_exact<E>), dim3((N + 7) / 8), dim3(64), 0, s, xq, xd, wq, wd, N, K, e); break; } \
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_qgemm_exact<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
+        hipLaunchKernelGGL((k_qgemm_exact<E>), grid, dim3(256), lds, s, xq, xd, M, wq, wd, N, K, e); } break;
     switch (mode) {
         WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_ENC_QKV) WA_CASE(WA_EPI_GELU_F32) WA_CASE(WA_EPI_RESID) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_CROSS_KV) WA_CASE(WA_EPI_DEC_QKV)
         default: break;
     }
 #undef WA_CASE
 }
-void wa_launch_qgemm_exact(hipStream_t stream, wa_epi_mode mode, const int8_t * xq, const float * xd, int M, int wtype, const uint8_t * wqs,
-                           const uint32_t * wqh, const float * wqd, int N, int K, const wa_epi & e) {
-    if (wtype == 6) qgemm_dispatch<6>(stream, mode, xq, xd, M, wqs, wqh, wqd, N, K, e);
-    else            qgemm_dispatch<8>(stream, mode, xq, xd, M, wqs, wqh, wqd, N, K, e);
-}
 
 // -------------------------------------------------------------------------------------------------
-// ggml_get_rows on the quantised token embedding (dequantize_row_q5_0 / q8_0, ggml-quants.c) + positional embedding
+// ggml_get_rows on the quantised token embedding (dequantize_row_q5_0 / q8_0, ggml-quants.c: q * d) + positional embedding
 // -------------------------------------------------------------------------------------------------
-__global__ void k_dec_embed_q(const int32_t * __restrict__ tok, const int32_t * __restrict__ pos, int n_tokens, int d, int wtype,
-                              const uint8_t * __restrict__ wqs, const uint32_t * __restrict__ wqh, const float * __restrict__ wqd,
-                              const float * __restrict__ pe, float * __restrict__ x) {
+__global__ void k_dec_embed_q(const int32_t * __restrict__ tok, const int32_t * __restrict__ pos, int n_tokens, int d,
+                              const int8_t * __restrict__ wq, const float * __restrict__ wd, const float * __restrict__ pe, float * __restrict__ x) {
     const int j = blockIdx.x;
     const int t = tok[j], p = pos[j], nb = d >> 5;
     for (int i = threadIdx.x; i < d; i += blockDim.x) {
-        const size_t blk = (size_t) t * nb + (i >> 5);
-        const int el = i & 31;
-        int q;
-        if (wtype == 6) {
-            const uint8_t byte = wqs[blk * 16 + (el & 15)];
-            q = (int) ((el < 16 ? byte & 0x0f : byte >> 4) | (((wqh[blk] >> el) & 1u) << 4)) - 16;
-        } else q = (int) (int8_t) wqs[blk * 32 + el];
-        x[(size_t) j * d + i] = (float) q * wqd[blk] + pe[(size_t) p * d + i];
+        const int b = i >> 5, el = i & 31;
+        const int q = (int) wq[(((size_t) t * 8 + (el >> 2)) * nb + b) * 4 + (el & 3)];
+        x[(size_t) j * d + i] = (float) q * wd[(size_t) t * nb + b] + pe[(size_t) p * d + i];
     }
 }
-void wa_launch_dec_embed_q(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d, int wtype, const uint8_t * wqs,
-                           const uint32_t * wqh, const float * wqd, const float * pe, float * x) {
-    hipLaunchKernelGGL(k_dec_embed_q, dim3(n_tokens), dim3(256), 0, stream, tok, pos, n_tokens, d, wtype, wqs, wqh, wqd, pe, x);
+void wa_launch_dec_embed_q(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d, const int8_t * wq, const float * wd,
+                           const float * pe, float * x) {
+    hipLaunchKernelGGL(k_dec_embed_q, dim3(n_tokens), dim3(256), 0, stream, tok, pos, n_tokens, d, wq, wd, pe, x);
 }
