@@ -117,7 +117,7 @@ void wa_launch_gemm_exact(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int
 // =================================================================================================
 // LayerNorm statistics of one row by one wave, reference-order semantics.  The row is read ONCE into registers
 // (NPL values per lane, d <= 64 * NPL) and mirrored into `lrow` (LDS, d floats) for the fallback; returns mean and scale.
-#define LN_NPL 20
+template <int LN_NPL>
 __device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d, float eps, int lane, float * lrow, float (&xv)[LN_NPL],
                                             float & mean, float & scale) {
     double s = 0.0, a = 0.0;
@@ -146,6 +146,7 @@ __device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d
     scale = 1.0f / sqrtf(variance + eps);
 }
 
+template <int LN_NPL>
 __global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
                                                          const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
                                                          float * __restrict__ out32, int ld32, int8_t * __restrict__ qs, float * __restrict__ qd) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restric
     float xv[LN_NPL], gw[LN_NPL], gb[LN_NPL], mean, scale;
 #pragma unroll
     for (int k = 0; k < LN_NPL; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; gw[k] = w[ic]; gb[k] = b[ic]; }
-    wa_ln_stats(xr, d, eps, lane, lrows[wave], xv, mean, scale);
+    wa_ln_stats<LN_NPL>(xr, d, eps, lane, lrows[wave], xv, mean, scale);
 #pragma unroll
     for (int k = 0; k < LN_NPL; ++k) {
         const int i = lane + 64 * k;
@@ -174,7 +175,10 @@ __global__ __launch_bounds__(256) void k_layernorm_exact(const float * __restric
 }
 void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
                                wa_f16 * out16, int ld16, float * out32, int ld32, int8_t * qs, float * qd) {
-    hipLaunchKernelGGL(k_layernorm_exact, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32, qs, qd);
+    // elements per lane sized to the row (d <= 1280): 6 for d <= 384, 12 for <= 768, 16 for <= 1024
+#define WA_LN_CASE(NPL) hipLaunchKernelGGL((k_layernorm_exact<NPL>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32, qs, qd)
+    if (d <= 384) WA_LN_CASE(6); else if (d <= 768) WA_LN_CASE(12); else if (d <= 1024) WA_LN_CASE(16); else WA_LN_CASE(20);
+#undef WA_LN_CASE
 }
 
 // =================================================================================================

@@ -107,6 +107,122 @@ __global__ __launch_bounds__(256) void k_gemm_f16(const wa_f16 * __restrict__ A,
         }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same product with the operand tiles brought in by LDS-DMA (global_load_lds_dwordx4: HBM / L2 -> LDS without staging registers)
+// through a ring of G2_NST stages, so G2_NST - 1 k-steps of loads are in flight behind the MFMAs of the current one; with register
+// staging (above) every k-step waits out a full memory round trip, which is what bounds the encoder's GEMMs (K = 768 .. 3072, 64x64
+// tiles to fill 256 CUs).  K % 64 == 0.  A wave-instruction writes 64 lanes x 16 B = 8 tile rows of 128 B contiguously; the
+// 16-byte slot of row r holding k-chunk c is c ^ ((r >> 1) & 7), which makes the MFMA fragment reads (16 rows, one chunk)
+// hit 16 distinct slots of the 256-byte bank space.  One LDS-only barrier per k-step.
+// -------------------------------------------------------------------------------------------------
+#define G2_BK  64
+#define G2_NST 4
+typedef __attribute__((address_space(1))) const void g2_gptr;
+typedef __attribute__((address_space(3))) void g2_lptr;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f16_dma(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
+                                                      int M, int N, int K, wa_epi e) {
+    __shared__ __attribute__((aligned(1024))) wa_f16 S[G2_NST][2][64 * G2_BK];      // 4 x (8 KB + 8 KB)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (N + 63) / 64;
+    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    const int m0 = bm * 64, n0 = bn * 64;
+
+    // this lane's two row groups (8 rows each) of either operand: group g = 2 * wave + i, row = 8 g + lane / 8, slot = lane % 8
+    const wa_f16 * ga[2], * gb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        ga[i] = A + (size_t) min(m0 + row, M - 1) * lda + chunk * 8;
+        gb[i] = W + (size_t) min(n0 + row, N - 1) * ldw + chunk * 8;
+    }
+    const int nk = K / G2_BK;
+#define G2_ISSUE(kt_) do { const int k0_ = min((kt_), nk - 1) * G2_BK; const int st_ = (kt_) % G2_NST; \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+            __builtin_amdgcn_global_load_lds((g2_gptr *) (ga[i] + k0_), (g2_lptr *) (&S[st_][0][(2 * wave + i) * 8 * G2_BK]), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((g2_gptr *) (gb[i] + k0_), (g2_lptr *) (&S[st_][1][(2 * wave + i) * 8 * G2_BK]), 16, 0, 0); \
+        } } while (0)
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int p = 0; p < G2_NST - 1; ++p) G2_ISSUE(p);
+
+    const int fr = lane & 15, fg = lane >> 4, sw = (fr >> 1) & 7;
+    // The V third of the encoder's fused q|k|v product is stored transposed ([d][T], the P V product's B operand): its blocks compute
+    // the transposed tile (operand roles swapped), so that the 16 lanes of an accumulator row hold consecutive t - 32-byte runs
+    // instead of 2-byte stores a row apart.
+    const bool tr = EPI == WA_EPI_ENC_QKV && n0 >= e.split0;
+    const int oa = tr ? 1 : 0, ra = (tr ? wn : wm) * 32, rb = (tr ? wm : wn) * 32;
+    // epilogue operands now (clamped indices, unconditional: a predicated load after the loop would cost a serial round trip each)
+    wa_epi_pre pre[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pre[i][j][r] = tr ? epi_preload<EPI>(e, min(m0 + wm * 32 + j * 16 + fr, M - 1), min(n0 + wn * 32 + i * 16 + fg * 4 + r, N - 1))
+                                  : epi_preload<EPI>(e, min(m0 + wm * 32 + i * 16 + fg * 4 + r, M - 1), min(n0 + wn * 32 + j * 16 + fr, N - 1));
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed when at most the (G2_NST - 2) x 4 loads issued after it are outstanding (every stage issues 4, also past the end)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((G2_NST - 2) * 4) : "memory");
+        G2_ISSUE(kt + G2_NST - 1);          // into the stage read in the previous iteration: every wave is past it (barrier)
+        const wa_f16 * As = S[kt % G2_NST][oa], * Bs = S[kt % G2_NST][oa ^ 1];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const half8 *) (&As[(ra + i * 16 + fr) * G2_BK + (((ks * 4 + fg) ^ sw) * 8)]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *(const half8 *) (&Bs[(rb + j * 16 + fr) * G2_BK + (((ks * 4 + fg) ^ sw) * 8)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
+#undef G2_ISSUE
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = tr ? n0 + wn * 32 + i * 16 + fg * 4 + r : n0 + wn * 32 + j * 16 + fr;
+                const int m = tr ? m0 + wm * 32 + j * 16 + fr : m0 + wm * 32 + i * 16 + fg * 4 + r;
+                if (m < M && n < N) epi_apply<EPI>(e, m, n, acc[i][j][r], pre[i][j][r]);
+            }
+        }
+}
+
+static void gemm_dma_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
+    const int grid = ((M + 63) / 64) * ((N + 63) / 64);
+#define WA_GEMM_CASE(E) case E: hipLaunchKernelGGL((k_gemm_f16_dma<E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); break;
+    switch (mode) {
+        WA_GEMM_CASE(WA_EPI_F16)
+        WA_GEMM_CASE(WA_EPI_ENC_QKV)
+        WA_GEMM_CASE(WA_EPI_GELU_F16)
+        WA_GEMM_CASE(WA_EPI_RESID)
+        WA_GEMM_CASE(WA_EPI_CONV2)
+        WA_GEMM_CASE(WA_EPI_F32)
+        WA_GEMM_CASE(WA_EPI_CROSS_KV)
+        WA_GEMM_CASE(WA_EPI_DEC_QKV)
+        default: break;
+    }
+#undef WA_GEMM_CASE
+}
+
 template <int BM, int BN>
 static void gemm_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
                           const wa_epi & e) {
@@ -129,6 +245,8 @@ void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int 
                     const wa_epi & e) {
     // 128x128 tiles when that still yields >= 256 blocks (one per CU); 64x64 otherwise.
     const long big = (long) ((M + 127) / 128) * ((N + 127) / 128);
+    static const bool no_dma = getenv("WHISPER_AMD_NO_GEMM_DMA") != nullptr;
+    if (!no_dma && K % G2_BK == 0 && K / G2_BK >= G2_NST && lda % 8 == 0 && ldw % 8 == 0) { gemm_dma_dispatch(stream, mode, A, lda, W, ldw, M, N, K, e); return; }
     static const long thr = getenv("WHISPER_AMD_GEMM_THR") ? atol(getenv("WHISPER_AMD_GEMM_THR")) : 1000000;   // measured on ggml-small shapes (M = 1500): 64x64 tiles (>= 4 blocks per CU) beat 128x128 on every GEMM of the encoder
     if (big >= thr) gemm_dispatch<128, 128>(stream, mode, A, lda, W, ldw, M, N, K, e);
     else            gemm_dispatch<64, 64>(stream, mode, A, lda, W, ldw, M, N, K, e);
@@ -429,23 +547,24 @@ void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows,
 }
 
 // =================================================================================================
-// Encoder self-attention, d_head = 64 (whisper.cpp:2181-2206 semantics):
-//   S = Q K^T (F16 operands, F32 acc) ; P = softmax(scale * S) in F32 over ALL keys ; P -> F16 ;
+// Encoder self-attention, d_head = 64 (whisper.cpp:2181-2206 semantics, tolerance path):
+//   S = Q K^T (F16 operands, F32 acc) ; P = softmax(scale * S) in F32 over all keys ; P -> F16 ;
 //   O = P V (F16 operands, F32 acc) -> F16 (it is the next GEMM's A operand).
-// Two sweeps over the keys so that P is normalised BEFORE it is rounded to F16, as in the reference:
-// sweep 1 = running max / sum, sweep 2 = recompute S, normalise, round, P V.
-// Block = 4 waves x 16 query rows; K and V^T tiles of 64 keys staged in LDS (72-half rows:
-// conflict-free b128 reads); P crosses LDS once per tile (per-wave scratch).
+// One sweep over the keys with a running row maximum (base-2 exponentials, scale * log2(e) folded into one multiply):
+// P~ = 2^(s - m) goes to F16 unnormalised, O is rescaled when the maximum moves (skipped when it did not, which is the
+// rule after the first few tiles) and divided by the row sum at the end.  The kernel is VALU-bound (one exponential and
+// ~8 other operations per score against 1/8 MFMA per score), so everything per score that can go has gone: the row maximum
+// over the 16 lanes of a row is four DPP rotations, the row sum stays lane-local until the end.
+// Block = 4 waves x 16 query rows; K and V^T tiles of 64 keys in two LDS buffers each (72-half rows: conflict-free b128
+// reads), filled through registers a tile ahead with the loads of the tile after that in flight; one LDS-only barrier per
+// tile; P crosses LDS once per tile (per-wave scratch, no barrier: a wave's LDS operations complete in order).
 // =================================================================================================
 #define ATT_LD 72
 
-// flash path only: hardware exp2 (v_exp_f32, ~1 ulp) instead of the reference's 25-instruction polynomial
-__device__ __forceinline__ float fast_expf(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-
 __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk, int ldqk, const wa_f16 * __restrict__ vt, int ldvt, int T,
                                                   int d, float scale, wa_f16 * __restrict__ out, int ldo) {
-    __shared__ __attribute__((aligned(16))) wa_f16 Ks[64 * ATT_LD];
-    __shared__ __attribute__((aligned(16))) wa_f16 Vs[64 * ATT_LD];
+    __shared__ __attribute__((aligned(16))) wa_f16 Ks[2][64 * ATT_LD];
+    __shared__ __attribute__((aligned(16))) wa_f16 Vs[2][64 * ATT_LD];
     __shared__ __attribute__((aligned(16))) wa_f16 Ps[4][16 * ATT_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -461,116 +580,117 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
         qf[0] = *(const half8 *) (qp + fg * 8);
         qf[1] = *(const half8 *) (qp + 32 + fg * 8);
     }
-
     const int n_tiles = (T + 63) / 64;
+    const float c2 = scale * 1.44269504088896340736f;
+
+    // All loads are unconditional (clamped tile index): a predicated load makes the compiler wait for every outstanding one.
+    typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+    att_u4 kreg0, kreg1, vreg0, vreg1;      // (plain vector values: arrays of HIP's uint4 class end up in scratch / LDS here)
+    const int c0 = tid, c1 = tid + 256;
+    const wa_f16 * kbase = qk + d + h * 64;
+    const wa_f16 * vbase = vt + (size_t) h * 64 * ldvt;
+#define FETCH_KV(kt_) do { const int t_ = min((kt_), n_tiles - 1) * 64; \
+        kreg0 = *(const att_u4 *) (kbase + (size_t) min(t_ + (c0 >> 3), T - 1) * ldqk + (c0 & 7) * 8); \
+        kreg1 = *(const att_u4 *) (kbase + (size_t) min(t_ + (c1 >> 3), T - 1) * ldqk + (c1 & 7) * 8); \
+        vreg0 = *(const att_u4 *) (vbase + (size_t) (c0 >> 3) * ldvt + t_ + (c0 & 7) * 8); \
+        vreg1 = *(const att_u4 *) (vbase + (size_t) (c1 >> 3) * ldvt + t_ + (c1 & 7) * 8); } while (0)
+#define STORE_KV(buf_) do { \
+        *(att_u4 *) (&Ks[buf_][(c0 >> 3) * ATT_LD + (c0 & 7) * 8]) = kreg0; *(att_u4 *) (&Ks[buf_][(c1 >> 3) * ATT_LD + (c1 & 7) * 8]) = kreg1; \
+        *(att_u4 *) (&Vs[buf_][(c0 >> 3) * ATT_LD + (c0 & 7) * 8]) = vreg0; *(att_u4 *) (&Vs[buf_][(c1 >> 3) * ATT_LD + (c1 & 7) * 8]) = vreg1; } while (0)
+
     float m_run[4], l_run[4];
+    f32x4 o_acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o_acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // K / V^T tiles go global -> registers -> LDS: the loads of tile kt + 1 are issued before tile kt is computed, so their HBM / L2
-    // round trip (1-2 us, once per tile and sweep: most of this kernel's time when it was exposed) hides behind the MFMAs
-    uint4 kreg[2], vreg[2];
-    auto fetch_k = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-            int key = kt * 64 + row; key = key < T ? key : T - 1;
-            kreg[i] = *(const uint4 *) (qk + (size_t) key * ldqk + d + h * 64 + kc * 8);
-        }
-    };
-    auto fetch_v = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;   // row = dh, kc = key chunk
-            vreg[i] = *(const uint4 *) (vt + (size_t) (h * 64 + row) * ldvt + kt * 64 + kc * 8);
-        }
-    };
-    auto store_k = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int c = tid + 256 * i; *(uint4 *) (&Ks[(c >> 3) * ATT_LD + (c & 7) * 8]) = kreg[i]; }
-    };
-    auto store_v = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int c = tid + 256 * i; *(uint4 *) (&Vs[(c >> 3) * ATT_LD + (c & 7) * 8]) = vreg[i]; }
-    };
-    auto scores = [&](int kt, f32x4 (&s)[4]) {
+    FETCH_KV(0); STORE_KV(0); FETCH_KV(1);
+    wa_barrier_lds();
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int buf = kt & 1;
+        f32x4 s[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const half8 b = *(const half8 *) (&Ks[(nt * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
+                const half8 b = *(const half8 *) (&Ks[buf][(nt * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[ks], b, a, 0, 0, 0);
             }
-            const bool valid = kt * 64 + nt * 16 + fr < T;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[nt][r] = valid ? a[r] * scale : -INFINITY;
+            for (int r = 0; r < 4; ++r) s[nt][r] = a[r] * c2;
         }
-    };
-
-    // ---- sweep 1: row max and sum of exp ----
-    fetch_k(0);
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        __syncthreads();
-        store_k();
-        if (kt + 1 < n_tiles) fetch_k(kt + 1);
-        wa_barrier_lds();
-        f32x4 s[4];
-        scores(kt, s);
+        if (kt == n_tiles - 1) {        // only the last tile has keys past the end
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (kt * 64 + nt * 16 + fr >= T) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[nt][r] = -INFINITY;
+                }
+        }
+        float corr[4];
+        bool moved = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float mx = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
-            const float m_new = fmaxf(m_run[r], mx);
-            float ls = fast_expf(s[0][r] - m_new) + fast_expf(s[1][r] - m_new) + fast_expf(s[2][r] - m_new) + fast_expf(s[3][r] - m_new);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) ls += __shfl_xor(ls, o, WAVE);
-            const float corr = (m_run[r] == -INFINITY) ? 0.f : fast_expf(m_run[r] - m_new);
-            l_run[r] = l_run[r] * corr + ls;
+            float t = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
+            t = fmaxf(t, dpp_f32<0x128>(t));        // row_ror:8, 4, 2, 1: the maximum over the row's 16 lanes, in every one of them
+            t = fmaxf(t, dpp_f32<0x124>(t));
+            t = fmaxf(t, dpp_f32<0x122>(t));
+            t = fmaxf(t, dpp_f32<0x121>(t));
+            const float m_new = fmaxf(m_run[r], t);        // finite from the first tile on: keys 0..63 exist for every row
+            moved = moved || (m_new != m_run[r]);
+            corr[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);
             m_run[r] = m_new;
         }
-    }
-    float inv_l[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) inv_l[r] = (float) (1.0 / (double) l_run[r]);   // ops.cpp:4815-4818
-
-    // ---- sweep 2: P = exp(s - m) / l -> F16 ; O += P V ----
-    f32x4 o_acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o_acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    fetch_k(0); fetch_v(0);
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        __syncthreads();
-        store_k(); store_v();
-        if (kt + 1 < n_tiles) { fetch_k(kt + 1); fetch_v(kt + 1); }
-        wa_barrier_lds();
-        f32x4 s[4];
-        scores(kt, s);
+        float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = fast_expf(s[nt][r] - m_run[r]) * inv_l[r];
+                const float p = __builtin_amdgcn_exp2f(s[nt][r] - m_run[r]);
+                ls[r] += p;
                 Ps[wave][(fg * 4 + r) * ATT_LD + nt * 16 + fr] = f2h(p);
             }
-        wa_barrier_lds();
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {      // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                l_run[r] = l_run[r] * corr[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o_acc[j][r] = o_acc[j][r] * corr[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) l_run[r] += ls[r];
+        asm volatile("" ::: "memory");       // Ps[wave] is private to the wave and LDS operations of a wave complete in order: no barrier
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const half8 a = *(const half8 *) (&Ps[wave][fr * ATT_LD + ks * 32 + fg * 8]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const half8 b = *(const half8 *) (&Vs[(j * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
+                const half8 b = *(const half8 *) (&Vs[buf][(j * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
                 o_acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, o_acc[j], 0, 0, 0);
             }
         }
+        STORE_KV(buf ^ 1);
+        FETCH_KV(kt + 2);
+        wa_barrier_lds();
+    }
+#undef FETCH_KV
+#undef STORE_KV
+    float inv_l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float l = l_run[r];
+        l += dpp_f32<0x128>(l); l += dpp_f32<0x124>(l); l += dpp_f32<0x122>(l); l += dpp_f32<0x121>(l);
+        inv_l[r] = (float) (1.0 / (double) l);   // ops.cpp:4815-4818
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = q0 + fg * 4 + r;
-            if (q < T) out[(size_t) q * ldo + h * 64 + j * 16 + fr] = f2h(o_acc[j][r]);
+            if (q < T) out[(size_t) q * ldo + h * 64 + j * 16 + fr] = f2h(o_acc[j][r] * inv_l[r]);
         }
 }
 
