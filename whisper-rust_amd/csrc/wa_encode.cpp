@@ -292,7 +292,8 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
     } else {
     for (int il = 0; il < hp.n_audio_layer; ++il) {
         const auto & L = m.enc[il];
-        wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        if (exact) wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        else       wa_launch_layernorm(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
         if (exact) {   // Q | K | V row-major in one [T][3d] buffer (the FFN buffer is free here)
             wa_epi e; e.bias = L.qkv.b; e.out = st.d_ff; e.ldo = 3 * d;
             wa_launch_gemm_exact(s, WA_EPI_F16, st.d_xn, d, L.qkv.w, d, T, 3 * d, d, e);
@@ -307,7 +308,8 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
             wa_epi e; e.bias = L.out.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d;
             gemm(WA_EPI_RESID, st.d_ao, d, L.out.w, d, T, d, d, e);
         }
-        wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        if (exact) wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
+        else       wa_launch_layernorm(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
         {
             wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_ff; e.ldo = 4 * d;
             gemm(WA_EPI_GELU_F16, st.d_xn, d, L.fc1.w, d, T, 4 * d, d, e);
@@ -318,7 +320,8 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
         }
     }
     // ln_post -> F32 encoder output (API / tests) + F16 copy (operand of the cross K/V GEMM)
-    wa_launch_layernorm_exact(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, st.d_xn, d, st.d_embd_enc, d);
+    if (exact) wa_launch_layernorm_exact(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, st.d_xn, d, st.d_embd_enc, d);
+    else       wa_launch_layernorm(s, st.d_x, d, T, d, m.e_ln.w, m.e_ln.b, hp.eps, st.d_xn, d, st.d_embd_enc, d);
 
     // cross-attention K/V of ALL decoder layers in one GEMM (whisper.cpp:2290-2364):
     // K = (Wk enc) * d_h^-1/4, V = Wv enc + b, both F16, laid out [layer][head][t][64]

@@ -59,11 +59,11 @@ void wa_launch_mel(hipStream_t stream, const float * pcm, int n_samples, const f
 void wa_launch_mel_window(hipStream_t stream, const float * mel, int n_mel, int n_len, int seek, int n_frames,
                           wa_f16 * melT, int rows_total);
 
-// ---- LayerNorm: y = ((x - mean) * rsqrt(var + eps)) * w + b;  out16 f16 and/or out32 f32 -----------
+// ---- LayerNorm of the tolerance path (F32 sums): y = ((x - mean) * rsqrt(var + eps)) * w + b;  out16 f16 and/or out32 f32; d % 4 == 0
 void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b,
                          float eps, wa_f16 * out16, int ld16, float * out32, int ld32);
 
-// ---- encoder self-attention (exact softmax, two sweeps): qk [T][2d] (Q | K), vt [d][tpad] ----------
+// ---- encoder self-attention (tolerance path, one sweep with a running maximum): qk [T][2d] (Q | K), vt [d][tpad] ----------
 void wa_launch_enc_attn(hipStream_t stream, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d,
                         int n_head, float scale, wa_f16 * out, int ldo);
 

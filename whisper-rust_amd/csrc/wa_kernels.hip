@@ -511,39 +511,50 @@ void wa_launch_mel_window(hipStream_t stream, const float * mel, int n_mel, int 
 }
 
 // =================================================================================================
-// LayerNorm (ops.cpp:3199-3248 + the separate mul / add of whisper.cpp:2121-2126): one wave per row.
-// mean and variance accumulate in F64 like ggml_float; the three elementwise steps round separately.
-// HBM-bound: reads d f32, writes d f16 (and optionally d f32).
+// LayerNorm of the tolerance path (flash_attn = true): one wave per row, 16-byte loads, F32 sums (two-pass variance as in
+// ops.cpp:3225-3242, but in F32 and in wave order - within the path's 1e-3 contract; the reference-order kernel with its
+// certified F64 sums is k_layernorm_exact).  d % 4 == 0, d <= 256 NV.
 // =================================================================================================
+template <int NV>
 __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x, int ldx, int rows, int d, const float * __restrict__ w,
                                                    const float * __restrict__ b, float eps, wa_f16 * __restrict__ out16, int ld16,
                                                    float * __restrict__ out32, int ld32) {
+    typedef float ln_f4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 ln_h4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const float * xr = x + (size_t) row * ldx;
-    double s = 0.0;
-    for (int i = lane; i < d; i += 64) s += (double) xr[i];
-    s = wave_sum_d(s);
-    const float mean = (float) (s / (double) d);
-    double s2 = 0.0;
-    for (int i = lane; i < d; i += 64) { const float v = xr[i] - mean; s2 += (double) (v * v); }
-    s2 = wave_sum_d(s2);
-    const float variance = (float) (s2 / (double) d);
-    const float scale = 1.0f / sqrtf(variance + eps);
-    for (int i = lane; i < d; i += 64) {
-        float y = xr[i] - mean;
-        y = y * scale;
-        y = y * w[i];
-        y = y + b[i];
-        if (out16) out16[(size_t) row * ld16 + i] = f2h(y);
-        if (out32) out32[(size_t) row * ld32 + i] = y;
+    const int nv = d >> 2;
+    ln_f4 xv[NV], gw[NV], gb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {      // unconditional loads (clamped index): all in flight together
+        const int i = lane + 64 * k, ic = i < nv ? i : nv - 1;
+        xv[k] = *(const ln_f4 *) (xr + 4 * ic); gw[k] = *(const ln_f4 *) (w + 4 * ic); gb[k] = *(const ln_f4 *) (b + 4 * ic);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) if (lane + 64 * k < nv) s += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
+    const float mean = wave_sum(s) / (float) d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) if (lane + 64 * k < nv) { const ln_f4 v = xv[k] - mean; s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+    const float scale = 1.0f / sqrtf(wave_sum(s2) / (float) d + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        if (i < nv) {
+            const ln_f4 y = (xv[k] - mean) * scale * gw[k] + gb[k];
+            if (out16) { ln_h4 h; h.x = (_Float16) y.x; h.y = (_Float16) y.y; h.z = (_Float16) y.z; h.w = (_Float16) y.w; *(ln_h4 *) (out16 + (size_t) row * ld16 + 4 * i) = h; }
+            if (out32) *(ln_f4 *) (out32 + (size_t) row * ld32 + 4 * i) = y;
+        }
     }
 }
-
 void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows, int d, const float * w, const float * b, float eps,
                          wa_f16 * out16, int ld16, float * out32, int ld32) {
-    hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32);
+#define WA_LN_CASE(NV) hipLaunchKernelGGL((k_layernorm<NV>), dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, rows, d, w, b, eps, out16, ld16, out32, ld32)
+    if (d <= 512) WA_LN_CASE(2); else if (d <= 768) WA_LN_CASE(3); else if (d <= 1024) WA_LN_CASE(4); else WA_LN_CASE(5);
+#undef WA_LN_CASE
 }
 
 // =================================================================================================
@@ -553,8 +564,9 @@ void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows,
 // One sweep over the keys with a running row maximum (base-2 exponentials, scale * log2(e) folded into one multiply):
 // P~ = 2^(s - m) goes to F16 unnormalised, O is rescaled when the maximum moves (skipped when it did not, which is the
 // rule after the first few tiles) and divided by the row sum at the end.  The kernel is VALU-bound (one exponential and
-// ~8 other operations per score against 1/8 MFMA per score), so everything per score that can go has gone: the row maximum
-// over the 16 lanes of a row is four DPP rotations, the row sum stays lane-local until the end.
+// ~8 other operations per score against 1/8 MFMA per score), so everything per score that can go has gone: one FMA + one
+// v_exp_f32 + one conversion per score, the row maximum over the 16 lanes of a row is four DPP rotations, and the row sums
+// come from the matrix pipe (P times a column of ones).
 // Block = 4 waves x 16 query rows; K and V^T tiles of 64 keys in two LDS buffers each (72-half rows: conflict-free b128
 // reads), filled through registers a tile ahead with the loads of the tile after that in flight; one LDS-only barrier per
 // tile; P crosses LDS once per tile (per-wave scratch, no barrier: a wave's LDS operations complete in order).
@@ -598,28 +610,29 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
         *(att_u4 *) (&Ks[buf_][(c0 >> 3) * ATT_LD + (c0 & 7) * 8]) = kreg0; *(att_u4 *) (&Ks[buf_][(c1 >> 3) * ATT_LD + (c1 & 7) * 8]) = kreg1; \
         *(att_u4 *) (&Vs[buf_][(c0 >> 3) * ATT_LD + (c0 & 7) * 8]) = vreg0; *(att_u4 *) (&Vs[buf_][(c1 >> 3) * ATT_LD + (c1 & 7) * 8]) = vreg1; } while (0)
 
-    float m_run[4], l_run[4];
-    f32x4 o_acc[4];
+    float m_run[4];
+    f32x4 o_acc[4], l_acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+    for (int r = 0; r < 4; ++r) m_run[r] = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o_acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (_Float16) 1.0f;
 
     FETCH_KV(0); STORE_KV(0); FETCH_KV(1);
     wa_barrier_lds();
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int buf = kt & 1;
-        f32x4 s[4];
+        f32x4 s[4];         // raw dot products; the soft-max runs in base 2 on s * c2
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const half8 b = *(const half8 *) (&Ks[buf][(nt * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[ks], b, a, 0, 0, 0);
+                s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[ks], b, s[nt], 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[nt][r] = a[r] * c2;
         }
         if (kt == n_tiles - 1) {        // only the last tile has keys past the end
 #pragma unroll
@@ -629,39 +642,38 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
                     for (int r = 0; r < 4; ++r) s[nt][r] = -INFINITY;
                 }
         }
-        float corr[4];
+        float corr[4], mc[4];
         bool moved = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float t = fmaxf(fmaxf(s[0][r], s[1][r]), fmaxf(s[2][r], s[3][r]));
-            t = fmaxf(t, dpp_f32<0x128>(t));        // row_ror:8, 4, 2, 1: the maximum over the row's 16 lanes, in every one of them
-            t = fmaxf(t, dpp_f32<0x124>(t));
-            t = fmaxf(t, dpp_f32<0x122>(t));
-            t = fmaxf(t, dpp_f32<0x121>(t));
+            // the maximum over the row's 16 lanes, in every one of them: four rotations, one VALU operation each (s_nop 1: a DPP read of
+            // a VGPR needs two wait states after the VALU write)
+            asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(t));
             const float m_new = fmaxf(m_run[r], t);        // finite from the first tile on: keys 0..63 exist for every row
             moved = moved || (m_new != m_run[r]);
-            corr[r] = __builtin_amdgcn_exp2f(m_run[r] - m_new);
+            corr[r] = __builtin_amdgcn_exp2f((m_run[r] - m_new) * c2);
             m_run[r] = m_new;
+            mc[r] = -m_new * c2;
         }
-        float ls[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[nt][r] - m_run[r]);
-                ls[r] += p;
-                Ps[wave][(fg * 4 + r) * ATT_LD + nt * 16 + fr] = f2h(p);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[nt][r], c2, mc[r]));
+                Ps[wave][(fg * 4 + r) * ATT_LD + nt * 16 + fr] = __builtin_bit_cast(wa_f16, (_Float16) p);
             }
         if (__builtin_amdgcn_ballot_w64(moved) != 0) {      // wave-uniform
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                l_run[r] = l_run[r] * corr[r];
+                l_acc[r] = l_acc[r] * corr[r];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o_acc[j][r] = o_acc[j][r] * corr[r];
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) l_run[r] += ls[r];
         asm volatile("" ::: "memory");       // Ps[wave] is private to the wave and LDS operations of a wave complete in order: no barrier
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -671,6 +683,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
                 const half8 b = *(const half8 *) (&Vs[buf][(j * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
                 o_acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, o_acc[j], 0, 0, 0);
             }
+            l_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ones, l_acc, 0, 0, 0);      // row sums of the F16 probabilities, on the matrix pipe
         }
         STORE_KV(buf ^ 1);
         FETCH_KV(kt + 2);
@@ -680,11 +693,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
 #undef STORE_KV
     float inv_l[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float l = l_run[r];
-        l += dpp_f32<0x128>(l); l += dpp_f32<0x124>(l); l += dpp_f32<0x122>(l); l += dpp_f32<0x121>(l);
-        inv_l[r] = (float) (1.0 / (double) l);   // ops.cpp:4815-4818
-    }
+    for (int r = 0; r < 4; ++r) inv_l[r] = (float) (1.0 / (double) l_acc[r]);   // ops.cpp:4815-4818 (every column of l_acc holds the row sum)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
