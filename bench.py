@@ -214,9 +214,12 @@ def main():
             traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "r01_decode_step_pmc.json")
             if args.model == "small" and os.path.exists(pmc) and lib.whisper_amd_mega_enabled(st.ptr):
-                pj = json.load(open(pmc))
-                traffic = int((2 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024)
-                traffic_src = "profiles/r01_decode_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2)"
+                try:
+                    pj = json.load(open(pmc))
+                    traffic = int((2 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024)
+                    traffic_src = "profiles/r01_decode_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2)"
+                except (KeyError, ValueError):
+                    traffic, traffic_src = None, None
             kname = ("k_decode_mega: the whole single-token decoder pass as ONE persistent launch (256 workgroups, granule hand-offs), n_past=64"
                      if lib.whisper_amd_mega_enabled(st.ptr) else
                      "decode step = hipGraph of 122 launches (k_gemv_exact weight streaming + k_attn_exact), 1 token, n_past=64")
@@ -244,6 +247,21 @@ def main():
                           "peak_tflops": MFMA_F16_PEAK_TFLOPS,
                           "frac": round(eflops / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if enc_ms > 0 else None,
                           "mel_ms": round(1e-3 * t_mel, 3)}
+        # ---- the reference's whisper-bench protocol (examples/bench/bench.cpp: 256 single tokens, 64 batches of 5, 16 prompts of 256;
+        #      SURVEY.md 8d) through the public C API, host work included - figures that do not depend on how many tokens a model decodes
+        try:
+            tok = [int(ctx.lib.whisper_token_sot(ctx.ptr))] * 256
+            def _run(n_tok, n_past, reps):
+                st.decode(tok[:n_tok], n_past)
+                hip.sync(); t_ = time.perf_counter()
+                for _ in range(reps):
+                    st.decode(tok[:n_tok], n_past)
+                hip.sync()
+                return 1e3 * (time.perf_counter() - t_) / (reps * n_tok)
+            out["whisper_bench"] = {"decode_ms_per_token": round(_run(1, 64, 64), 4), "batch5_ms_per_token": round(_run(5, 64, 32), 4),
+                                    "prompt256_ms_per_token": round(_run(256, 0, 8), 4)}
+        except Exception as ex:  # extension only
+            out["whisper_bench"] = {"error": str(ex)}
         out["host_sampling_ms_per_token"] = round(1e-3 * t_sample / max(1, n_decode), 4)
         ov = (C.c_int * 2)()
         lib.whisper_amd_overlap_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int)]

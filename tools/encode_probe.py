@@ -6,10 +6,11 @@ import wsynth, whisper_rs as W
 name = sys.argv[1] if len(sys.argv) > 1 else "small"
 lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
 pcm = wsynth.synth_audio(480000, 0)
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 for flash in ([True, False] if len(sys.argv) < 3 else [bool(int(sys.argv[2]))]):
     ctx = W.WhisperContext.new_with_params(wsynth.model_path(name), W.WhisperContextParameters(lib, flash_attn=flash), lib=lib)
     st = ctx.create_state(); st.pcm_to_mel(pcm); st.encode(0)
     t = time.perf_counter()
-    for _ in range(10): st.encode(0)
-    print("%s flash_attn=%d: encode %.3f ms / 30 s chunk" % (name, flash, (time.perf_counter() - t) * 100))
+    for _ in range(iters): st.encode(0)
+    print("%s flash_attn=%d: encode %.3f ms / 30 s chunk" % (name, flash, (time.perf_counter() - t) * 1000 / iters))
     st.free(); ctx.free()

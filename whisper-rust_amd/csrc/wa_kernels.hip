@@ -127,8 +127,14 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(const wa_f16 * __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (N + 63) / 64;
-    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own 4 MB L2, and 64x64
+    // tiles re-read A N/64 times and W M/64 times: the product is bound by that re-read traffic (measured 8-9 TB/s at every shape, i.e.
+    // L2 misses served by the Infinity Cache).  So XCD x takes a contiguous eighth of the tiles, cut along the longer of M and N: it
+    // then streams the whole smaller operand's panel once and only its own eighth of the other, and both stay L2-resident.
+    const int tiles_m = (M + 63) / 64, tiles_n = (N + 63) / 64, per_xcd = (tiles_m * tiles_n + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= tiles_m * tiles_n) return;
+    const int bm = N > M ? t % tiles_m : t / tiles_n, bn = N > M ? t / tiles_m : t % tiles_n;
     const int m0 = bm * 64, n0 = bn * 64;
 
     // this lane's two row groups (8 rows each) of either operand: group g = 2 * wave + i, row = 8 g + lane / 8, slot = lane % 8
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16_dma(const wa_f16 * __restrict_
 }
 
 static void gemm_dma_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
-    const int grid = ((M + 63) / 64) * ((N + 63) / 64);
+    const int grid = ((((M + 63) / 64) * ((N + 63) / 64) + 7) / 8) * 8;        // a multiple of the 8 XCDs (see the tile order in the kernel)
 #define WA_GEMM_CASE(E) case E: hipLaunchKernelGGL((k_gemm_f16_dma<E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); break;
     switch (mode) {
         WA_GEMM_CASE(WA_EPI_F16)
@@ -567,22 +573,30 @@ void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows,
 // ~8 other operations per score against 1/8 MFMA per score), so everything per score that can go has gone: one FMA + one
 // v_exp_f32 + one conversion per score, the row maximum over the 16 lanes of a row is four DPP rotations, and the row sums
 // come from the matrix pipe (P times a column of ones).
-// Block = 4 waves x 16 query rows; K and V^T tiles of 64 keys in two LDS buffers each (72-half rows: conflict-free b128
-// reads), filled through registers a tile ahead with the loads of the tile after that in flight; one LDS-only barrier per
-// tile; P crosses LDS once per tile (per-wave scratch, no barrier: a wave's LDS operations complete in order).
+// Block = 4 waves x 16 query rows; K and V^T tiles of 64 keys by LDS-DMA into a ring of 4 stages (three tiles of loads in
+// flight, XOR-swizzled slots); one LDS-only barrier per tile; P crosses LDS once per tile (per-wave scratch, 72-half rows,
+// no barrier: a wave's LDS operations complete in order).
 // =================================================================================================
 #define ATT_LD 72
+#define ATT_NST 4
 
 __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk, int ldqk, const wa_f16 * __restrict__ vt, int ldvt, int T,
-                                                  int d, float scale, wa_f16 * __restrict__ out, int ldo) {
-    __shared__ __attribute__((aligned(16))) wa_f16 Ks[2][64 * ATT_LD];
-    __shared__ __attribute__((aligned(16))) wa_f16 Vs[2][64 * ATT_LD];
+                                                  int d, int n_head, float scale, wa_f16 * __restrict__ out, int ldo) {
+    // K and V^T tiles (64 rows x 128 B each) arrive by LDS-DMA in a ring of ATT_NST stages, three tiles ahead of the arithmetic; same
+    // XOR-swizzled 16-byte slots as k_gemm_f16_dma (LDS-DMA cannot pad rows)
+    __shared__ __attribute__((aligned(1024))) wa_f16 KV[ATT_NST][2][64 * 64];
     __shared__ __attribute__((aligned(16))) wa_f16 Ps[4][16 * ATT_LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int h = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int fr = lane & 15, fg = lane >> 4, sw = (fr >> 1) & 7;
+    // XCD-aware order (workgroup b -> XCD b % 8): an XCD takes a contiguous eighth of the (head, query tile) pairs, head-major, so a
+    // head's K / V (384 KB at T = 1500) is streamed into one or two L2s instead of all eight
+    const int n_tiles = (T + 63) / 64;
+    const int per_xcd = (n_head * n_tiles + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= n_head * n_tiles) return;
+    const int h = t / n_tiles;
+    const int q0 = (t % n_tiles) * 64 + wave * 16;
 
     // Q fragments: A operand, row = fr, k = dh
     half8 qf[2];
@@ -592,23 +606,26 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
         qf[0] = *(const half8 *) (qp + fg * 8);
         qf[1] = *(const half8 *) (qp + 32 + fg * 8);
     }
-    const int n_tiles = (T + 63) / 64;
     const float c2 = scale * 1.44269504088896340736f;
 
-    // All loads are unconditional (clamped tile index): a predicated load makes the compiler wait for every outstanding one.
-    typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
-    att_u4 kreg0, kreg1, vreg0, vreg1;      // (plain vector values: arrays of HIP's uint4 class end up in scratch / LDS here)
-    const int c0 = tid, c1 = tid + 256;
+    // this lane's two row groups (8 rows each) of either tile: group g = 2 * wave + i, row = 8 g + lane / 8, 16-byte slot = lane % 8
     const wa_f16 * kbase = qk + d + h * 64;
     const wa_f16 * vbase = vt + (size_t) h * 64 * ldvt;
-#define FETCH_KV(kt_) do { const int t_ = min((kt_), n_tiles - 1) * 64; \
-        kreg0 = *(const att_u4 *) (kbase + (size_t) min(t_ + (c0 >> 3), T - 1) * ldqk + (c0 & 7) * 8); \
-        kreg1 = *(const att_u4 *) (kbase + (size_t) min(t_ + (c1 >> 3), T - 1) * ldqk + (c1 & 7) * 8); \
-        vreg0 = *(const att_u4 *) (vbase + (size_t) (c0 >> 3) * ldvt + t_ + (c0 & 7) * 8); \
-        vreg1 = *(const att_u4 *) (vbase + (size_t) (c1 >> 3) * ldvt + t_ + (c1 & 7) * 8); } while (0)
-#define STORE_KV(buf_) do { \
-        *(att_u4 *) (&Ks[buf_][(c0 >> 3) * ATT_LD + (c0 & 7) * 8]) = kreg0; *(att_u4 *) (&Ks[buf_][(c1 >> 3) * ATT_LD + (c1 & 7) * 8]) = kreg1; \
-        *(att_u4 *) (&Vs[buf_][(c0 >> 3) * ATT_LD + (c0 & 7) * 8]) = vreg0; *(att_u4 *) (&Vs[buf_][(c1 >> 3) * ATT_LD + (c1 & 7) * 8]) = vreg1; } while (0)
+    int krow[2], kch[2];
+    const wa_f16 * gv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + (lane >> 3);
+        kch[i] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        krow[i] = row;
+        gv[i] = vbase + (size_t) row * ldvt + kch[i];
+    }
+#define ATT_ISSUE(kt_) do { const int t0_ = min((kt_), n_tiles - 1) * 64; const int st_ = (kt_) % ATT_NST; \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
+            __builtin_amdgcn_global_load_lds((g2_gptr *) (kbase + (size_t) min(t0_ + krow[i], T - 1) * ldqk + kch[i]), \
+                                             (g2_lptr *) (&KV[st_][0][(2 * wave + i) * 8 * 64]), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((g2_gptr *) (gv[i] + t0_), (g2_lptr *) (&KV[st_][1][(2 * wave + i) * 8 * 64]), 16, 0, 0); \
+        } } while (0)
 
     float m_run[4];
     f32x4 o_acc[4], l_acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -620,17 +637,20 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (_Float16) 1.0f;
 
-    FETCH_KV(0); STORE_KV(0); FETCH_KV(1);
-    wa_barrier_lds();
+#pragma unroll
+    for (int p = 0; p < ATT_NST - 1; ++p) ATT_ISSUE(p);
     for (int kt = 0; kt < n_tiles; ++kt) {
-        const int buf = kt & 1;
+        // tile kt has landed when at most the (ATT_NST - 2) x 4 loads issued after it are outstanding (every stage issues 4, also past the end)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((ATT_NST - 2) * 4) : "memory");
+        ATT_ISSUE(kt + ATT_NST - 1);        // into the stage read in the previous iteration: every wave is past it (barrier)
+        const wa_f16 * Ks = KV[kt % ATT_NST][0], * Vs = KV[kt % ATT_NST][1];
         f32x4 s[4];         // raw dot products; the soft-max runs in base 2 on s * c2
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const half8 b = *(const half8 *) (&Ks[buf][(nt * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
+                const half8 b = *(const half8 *) (&Ks[(nt * 16 + fr) * 64 + (((ks * 4 + fg) ^ sw) * 8)]);
                 s[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[ks], b, s[nt], 0, 0, 0);
             }
         }
@@ -680,17 +700,14 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
             const half8 a = *(const half8 *) (&Ps[wave][fr * ATT_LD + ks * 32 + fg * 8]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const half8 b = *(const half8 *) (&Vs[buf][(j * 16 + fr) * ATT_LD + ks * 32 + fg * 8]);
+                const half8 b = *(const half8 *) (&Vs[(j * 16 + fr) * 64 + (((ks * 4 + fg) ^ sw) * 8)]);
                 o_acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, o_acc[j], 0, 0, 0);
             }
             l_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ones, l_acc, 0, 0, 0);      // row sums of the F16 probabilities, on the matrix pipe
         }
-        STORE_KV(buf ^ 1);
-        FETCH_KV(kt + 2);
-        wa_barrier_lds();
     }
-#undef FETCH_KV
-#undef STORE_KV
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
+#undef ATT_ISSUE
     float inv_l[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) inv_l[r] = (float) (1.0 / (double) l_acc[r]);   // ops.cpp:4815-4818 (every column of l_acc holds the row sum)
@@ -705,7 +722,8 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
 
 void wa_launch_enc_attn(hipStream_t stream, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
                         wa_f16 * out, int ldo) {
-    hipLaunchKernelGGL(k_enc_attn, dim3((T + 63) / 64, n_head), dim3(256), 0, stream, qk, ldqk, vt, ldvt, T, d, scale, out, ldo);
+    const int grid = ((((T + 63) / 64) * n_head + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_enc_attn, dim3(grid), dim3(256), 0, stream, qk, ldqk, vt, ldvt, T, d, n_head, scale, out, ldo);
 }
 
 // =================================================================================================
