@@ -85,6 +85,12 @@ __device__ __forceinline__ float wa_expf(float x) {
 // GELU exactly as ggml_vec_gelu_f32 with GGML_GELU_FP16 (vec.h:571-585): table lookup on the F16
 // bits of x, identity above 10, zero below -10.  Result is an F32 that is exactly F16-representable
 // (or x itself for x >= 10).
+// the same value with the table read unconditional (any F16 bit pattern is a valid index): a batch of these stays in flight
+// together, where the branchy form costs one serial memory round trip per element
+__device__ __forceinline__ float wa_gelu_nb(float x, const wa_f16 * __restrict__ table) {
+    const float t = h2f(table[f2h(x)]);
+    return x <= -10.0f ? 0.0f : (x >= 10.0f ? x : t);
+}
 __device__ __forceinline__ float wa_gelu(float x, const wa_f16 * __restrict__ table) {
     if (x <= -10.0f) return 0.0f;
     if (x >=  10.0f) return x;

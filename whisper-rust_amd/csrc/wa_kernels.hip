@@ -109,122 +109,175 @@ __global__ __launch_bounds__(256) void k_gemm_f16(const wa_f16 * __restrict__ A,
 
 // -------------------------------------------------------------------------------------------------
 // The same product with the operand tiles brought in by LDS-DMA (global_load_lds_dwordx4: HBM / L2 -> LDS without staging registers)
-// through a ring of G2_NST stages, so G2_NST - 1 k-steps of loads are in flight behind the MFMAs of the current one; with register
-// staging (above) every k-step waits out a full memory round trip, which is what bounds the encoder's GEMMs (K = 768 .. 3072, 64x64
-// tiles to fill 256 CUs).  K % 64 == 0.  A wave-instruction writes 64 lanes x 16 B = 8 tile rows of 128 B contiguously; the
-// 16-byte slot of row r holding k-chunk c is c ^ ((r >> 1) & 7), which makes the MFMA fragment reads (16 rows, one chunk)
-// hit 16 distinct slots of the 256-byte bank space.  One LDS-only barrier per k-step.
+// through a ring of NST stages, so NST - 1 k-steps of loads are in flight behind the MFMAs of the current one; with register
+// staging (above) every k-step waits out a full memory round trip, which is what bounds the encoder's GEMMs (K = 768 .. 3072).
+// K % 64 == 0.  A wave-instruction writes 64 lanes x 16 B = 8 tile rows of 128 B contiguously; the 16-byte slot of row r holding
+// k-chunk c is c ^ ((r >> 1) & 7), which makes the MFMA fragment reads (16 rows, one chunk) hit 16 distinct slots of the 256-byte
+// bank space.  One LDS-only barrier per k-step.
+// Tiles: BT x BT x 64 per workgroup, 2 x 2 waves.  BT = 64 (wave tile 32 x 32: 4 fragment reads feed 4 MFMAs) where only that fills
+// 256 CUs (N = 768 products at M = 1500); BT = 128 (wave tile 64 x 64: 8 reads feed 16 MFMAs, a quarter of the barriers per flop)
+// for the wide products (q|k|v, first MLP product, cross K/V).
 // -------------------------------------------------------------------------------------------------
 #define G2_BK  64
-#define G2_NST 4
 typedef __attribute__((address_space(1))) const void g2_gptr;
 typedef __attribute__((address_space(3))) void g2_lptr;
 
-template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_f16_dma(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
+template <int EPI, int BT, int NST>
+__global__ __launch_bounds__(512) void k_gemm_f16_dma(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
                                                       int M, int N, int K, wa_epi e) {
-    __shared__ __attribute__((aligned(1024))) wa_f16 S[G2_NST][2][64 * G2_BK];      // 4 x (8 KB + 8 KB)
+    constexpr int TW = BT / 32;             // 16x16 tiles per MFMA wave and dimension
+    constexpr int LPO = BT / 32;            // DMA wave-instructions (8 rows each) per loader wave, operand and stage
+    constexpr bool RES = EPI == WA_EPI_RESID || EPI == WA_EPI_CONV2;       // epilogues with a per-element operand
+    static_assert(BT == 64 || !RES, "the 128-tile form keeps only per-column epilogue operands in registers");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
+    wa_f16 (*S)[2][BT * G2_BK] = (wa_f16 (*)[2][BT * G2_BK]) smem_raw;      // [NST][2][BT x 64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 8 waves: 0-3 multiply (2 x 2 grid of wave tiles), 4-7 only issue the LDS-DMA loads.  Issuing a 1 KiB piece holds a wave for
+    // 100-185 cycles (measured here: 2048 cycles per k-step of a 128-tile when the MFMA waves issued their own 8 pieces, 512 of them
+    // MFMA), so the loads get waves of their own and the two kinds of issue overlap on each SIMD.
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own 4 MB L2, and 64x64
-    // tiles re-read A N/64 times and W M/64 times: the product is bound by that re-read traffic (measured 8-9 TB/s at every shape, i.e.
-    // L2 misses served by the Infinity Cache).  So XCD x takes a contiguous eighth of the tiles, cut along the longer of M and N: it
-    // then streams the whole smaller operand's panel once and only its own eighth of the other, and both stay L2-resident.
-    const int tiles_m = (M + 63) / 64, tiles_n = (N + 63) / 64, per_xcd = (tiles_m * tiles_n + 7) >> 3;
+    // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own 4 MB L2: XCD x takes a
+    // contiguous eighth of the tiles, cut along the longer of M and N, so it streams the smaller operand's panel once and only its own
+    // eighth of the other (TCC hit rate 91 % on the encoder's products, profiles/).
+    const int tiles_m = (M + BT - 1) / BT, tiles_n = (N + BT - 1) / BT, per_xcd = (tiles_m * tiles_n + 7) >> 3;
     const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (t >= tiles_m * tiles_n) return;
     const int bm = N > M ? t % tiles_m : t / tiles_n, bn = N > M ? t / tiles_m : t % tiles_n;
-    const int m0 = bm * 64, n0 = bn * 64;
+    const int m0 = bm * BT, n0 = bn * BT;
 
-    // this lane's two row groups (8 rows each) of either operand: group g = 2 * wave + i, row = 8 g + lane / 8, slot = lane % 8
-    const wa_f16 * ga[2], * gb[2];
+    // this lane's LPO row groups (8 rows each) of either operand: group g = LPO * wave + i, row = 8 g + lane / 8, slot = lane % 8
+    const wa_f16 * ga[LPO], * gb[LPO];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (2 * wave + i) * 8 + (lane >> 3);
+    for (int i = 0; i < LPO; ++i) {
+        const int row = (LPO * wave + i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         ga[i] = A + (size_t) min(m0 + row, M - 1) * lda + chunk * 8;
         gb[i] = W + (size_t) min(n0 + row, N - 1) * ldw + chunk * 8;
     }
     const int nk = K / G2_BK;
-#define G2_ISSUE(kt_) do { const int k0_ = min((kt_), nk - 1) * G2_BK; const int st_ = (kt_) % G2_NST; \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) { \
-            __builtin_amdgcn_global_load_lds((g2_gptr *) (ga[i] + k0_), (g2_lptr *) (&S[st_][0][(2 * wave + i) * 8 * G2_BK]), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((g2_gptr *) (gb[i] + k0_), (g2_lptr *) (&S[st_][1][(2 * wave + i) * 8 * G2_BK]), 16, 0, 0); \
+#define G2_ISSUE(kt_) do { const int k0_ = min((kt_), nk - 1) * G2_BK; const int st_ = (kt_) % NST; \
+        _Pragma("unroll") for (int i = 0; i < LPO; ++i) { \
+            __builtin_amdgcn_global_load_lds((g2_gptr *) (ga[i] + k0_), (g2_lptr *) (&S[st_][0][(LPO * wave + i) * 8 * G2_BK]), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((g2_gptr *) (gb[i] + k0_), (g2_lptr *) (&S[st_][1][(LPO * wave + i) * 8 * G2_BK]), 16, 0, 0); \
         } } while (0)
 
-    f32x4 acc[2][2];
+    f32x4 acc[TW][TW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if (loader) {
 #pragma unroll
-    for (int p = 0; p < G2_NST - 1; ++p) G2_ISSUE(p);
+        for (int p = 0; p < NST - 1; ++p) G2_ISSUE(p);
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt has landed when at most the (NST - 2) x 2 LPO loads issued after it are outstanding (every stage issues 2 LPO, also past the end)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NST - 2) * 2 * LPO) : "memory");
+            G2_ISSUE(kt + NST - 1);         // into the stage read in the previous iteration: every MFMA wave is past it (barrier)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
+        return;
+    }
 
     const int fr = lane & 15, fg = lane >> 4, sw = (fr >> 1) & 7;
     // The V third of the encoder's fused q|k|v product is stored transposed ([d][T], the P V product's B operand): its blocks compute
     // the transposed tile (operand roles swapped), so that the 16 lanes of an accumulator row hold consecutive t - 32-byte runs
     // instead of 2-byte stores a row apart.
     const bool tr = EPI == WA_EPI_ENC_QKV && n0 >= e.split0;
-    const int oa = tr ? 1 : 0, ra = (tr ? wn : wm) * 32, rb = (tr ? wm : wn) * 32;
-    // epilogue operands now (clamped indices, unconditional: a predicated load after the loop would cost a serial round trip each)
-    wa_epi_pre pre[2][2][4];
+    const int oa = tr ? 1 : 0, ra = (tr ? wn : wm) * (BT / 2), rb = (tr ? wm : wn) * (BT / 2);
+    // epilogue operands now (clamped indices, unconditional: a predicated load after the loop would cost a serial round trip each).
+    // Per-column operands (bias, scale): one per n this lane owns; per-element ones (residual) only in the 64-tile form.
+    wa_epi_pre pcol[TW][4];        // non-transposed: [j][0] by column n(j); transposed: [i][r] by row n(i, r)
+    float pres[RES ? TW : 1][RES ? TW : 1][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int a = 0; a < TW; ++a)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int r = 0; r < 4; ++r)
+            if (tr || r == 0) pcol[a][r] = epi_preload<EPI == WA_EPI_RESID || EPI == WA_EPI_CONV2 ? WA_EPI_F32 : EPI>(e, 0, min(tr ? n0 + wn * (BT / 2) + a * 16 + fg * 4 + r : n0 + wn * (BT / 2) + a * 16 + fr, N - 1));
+    if (RES) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                pre[i][j][r] = tr ? epi_preload<EPI>(e, min(m0 + wm * 32 + j * 16 + fr, M - 1), min(n0 + wn * 32 + i * 16 + fg * 4 + r, N - 1))
-                                  : epi_preload<EPI>(e, min(m0 + wm * 32 + i * 16 + fg * 4 + r, M - 1), min(n0 + wn * 32 + j * 16 + fr, N - 1));
+        for (int i = 0; i < (RES ? TW : 1); ++i)
+#pragma unroll
+            for (int j = 0; j < (RES ? TW : 1); ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pres[i][j][r] = e.resid[(size_t) min(m0 + wm * (BT / 2) + i * 16 + fg * 4 + r, M - 1) * e.ldr + min(n0 + wn * (BT / 2) + j * 16 + fr, N - 1)];
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed when at most the (G2_NST - 2) x 4 loads issued after it are outstanding (every stage issues 4, also past the end)
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((G2_NST - 2) * 4) : "memory");
-        G2_ISSUE(kt + G2_NST - 1);          // into the stage read in the previous iteration: every wave is past it (barrier)
-        const wa_f16 * As = S[kt % G2_NST][oa], * Bs = S[kt % G2_NST][oa ^ 1];
+        asm volatile("s_barrier" ::: "memory");          // the loader waves have seen stage kt land
+        const wa_f16 * As = S[kt % NST][oa], * Bs = S[kt % NST][oa ^ 1];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8 af[2], bf[2];
+            half8 af[TW], bf[TW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const half8 *) (&As[(ra + i * 16 + fr) * G2_BK + (((ks * 4 + fg) ^ sw) * 8)]);
+            for (int i = 0; i < TW; ++i) af[i] = *(const half8 *) (&As[(ra + i * 16 + fr) * G2_BK + (((ks * 4 + fg) ^ sw) * 8)]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = *(const half8 *) (&Bs[(rb + j * 16 + fr) * G2_BK + (((ks * 4 + fg) ^ sw) * 8)]);
+            for (int j = 0; j < TW; ++j) bf[j] = *(const half8 *) (&Bs[(rb + j * 16 + fr) * G2_BK + (((ks * 4 + fg) ^ sw) * 8)]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TW; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
 #undef G2_ISSUE
-
+    if (EPI == WA_EPI_GELU_F16 || EPI == WA_EPI_CONV2) {       // GELU table look-ups of the whole tile first, all in flight together
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r];
+                    if (e.bias) v = v + pcol[j][0].bias;
+                    acc[i][j][r] = wa_gelu_nb(v, e.gelu);
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = tr ? n0 + wn * 32 + i * 16 + fg * 4 + r : n0 + wn * 32 + j * 16 + fr;
-                const int m = tr ? m0 + wm * 32 + j * 16 + fr : m0 + wm * 32 + i * 16 + fg * 4 + r;
-                if (m < M && n < N) epi_apply<EPI>(e, m, n, acc[i][j][r], pre[i][j][r]);
+                const int n = tr ? n0 + wn * (BT / 2) + i * 16 + fg * 4 + r : n0 + wn * (BT / 2) + j * 16 + fr;
+                const int m = tr ? m0 + wm * (BT / 2) + j * 16 + fr : m0 + wm * (BT / 2) + i * 16 + fg * 4 + r;
+                if (m >= M || n >= N) continue;
+                if (EPI == WA_EPI_GELU_F16) {
+                    ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(acc[i][j][r]);
+                } else if (EPI == WA_EPI_CONV2) {
+                    if (e.dbg) e.dbg[(size_t) m * e.ldo + n] = acc[i][j][r];
+                    ((float *) e.out)[(size_t) m * e.ldo + n] = pres[RES ? i : 0][RES ? j : 0][r] + acc[i][j][r];
+                } else {
+                    wa_epi_pre pre = tr ? pcol[i][r] : pcol[j][0];
+                    if (RES) pre.resid = pres[RES ? i : 0][RES ? j : 0][r];
+                    epi_apply<EPI>(e, m, n, acc[i][j][r], pre);
+                }
             }
         }
 }
 
+template <int BT, int NST>
 static void gemm_dma_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
-    const int grid = ((((M + 63) / 64) * ((N + 63) / 64) + 7) / 8) * 8;        // a multiple of the 8 XCDs (see the tile order in the kernel)
-#define WA_GEMM_CASE(E) case E: hipLaunchKernelGGL((k_gemm_f16_dma<E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); break;
+    const int grid = ((((M + BT - 1) / BT) * ((N + BT - 1) / BT) + 7) / 8) * 8;        // a multiple of the 8 XCDs (see the tile order in the kernel)
+    constexpr int lds = NST * 2 * BT * G2_BK * 2;
+#define WA_GEMM_CASE(E) case E: { \
+        static bool attr_done = false; \
+        if (!attr_done && lds > 64 * 1024) { (void) hipFuncSetAttribute((const void *) k_gemm_f16_dma<E, BT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
+        hipLaunchKernelGGL((k_gemm_f16_dma<E, BT, NST>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, M, N, K, e); } break;
     switch (mode) {
         WA_GEMM_CASE(WA_EPI_F16)
         WA_GEMM_CASE(WA_EPI_ENC_QKV)
         WA_GEMM_CASE(WA_EPI_GELU_F16)
-        WA_GEMM_CASE(WA_EPI_RESID)
-        WA_GEMM_CASE(WA_EPI_CONV2)
         WA_GEMM_CASE(WA_EPI_F32)
         WA_GEMM_CASE(WA_EPI_CROSS_KV)
         WA_GEMM_CASE(WA_EPI_DEC_QKV)
-        default: break;
+        default:
+            if constexpr (BT == 64) {
+                switch (mode) { WA_GEMM_CASE(WA_EPI_RESID) WA_GEMM_CASE(WA_EPI_CONV2) default: break; }
+            }
+            break;
     }
 #undef WA_GEMM_CASE
 }
@@ -252,7 +305,17 @@ void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int 
     // 128x128 tiles when that still yields >= 256 blocks (one per CU); 64x64 otherwise.
     const long big = (long) ((M + 127) / 128) * ((N + 127) / 128);
     static const bool no_dma = getenv("WHISPER_AMD_NO_GEMM_DMA") != nullptr;
-    if (!no_dma && K % G2_BK == 0 && K / G2_BK >= G2_NST && lda % 8 == 0 && ldw % 8 == 0) { gemm_dma_dispatch(stream, mode, A, lda, W, ldw, M, N, K, e); return; }
+    if (!no_dma && K % G2_BK == 0 && K / G2_BK >= 4 && lda % 8 == 0 && ldw % 8 == 0) {
+        // 64-tiles (4 stages = 64 KB, two workgroups per CU) everywhere.  128-tiles (3 stages = 96 KB, one workgroup per CU) halve the
+        // bytes a CU pulls in per flop, but measured slower on ggml-small's wide products at M = 1500 (first MLP product 30 vs 24 us,
+        // cross K/V 159 vs 119 us; q|k|v 17 vs 19): one workgroup per CU leaves the loader waves' issue rate and the epilogue exposed.
+        // WHISPER_AMD_GEMM_128=1 selects them for products without a per-element epilogue operand.
+        static const bool big_tiles = getenv("WHISPER_AMD_GEMM_128") != nullptr;
+        const bool res = mode == WA_EPI_RESID || mode == WA_EPI_CONV2;
+        if (big_tiles && !res && big >= 200) gemm_dma_dispatch<128, 3>(stream, mode, A, lda, W, ldw, M, N, K, e);
+        else                                 gemm_dma_dispatch<64, 4>(stream, mode, A, lda, W, ldw, M, N, K, e);
+        return;
+    }
     static const long thr = getenv("WHISPER_AMD_GEMM_THR") ? atol(getenv("WHISPER_AMD_GEMM_THR")) : 1000000;   // measured on ggml-small shapes (M = 1500): 64x64 tiles (>= 4 blocks per CU) beat 128x128 on every GEMM of the encoder
     if (big >= thr) gemm_dispatch<128, 128>(stream, mode, A, lda, W, ldw, M, N, K, e);
     else            gemm_dispatch<64, 64>(stream, mode, A, lda, W, ldw, M, N, K, e);
