@@ -643,14 +643,16 @@ void wa_launch_layernorm(hipStream_t stream, const float * x, int ldx, int rows,
 #define ATT_LD 72
 #define ATT_NST 4
 
-__global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk, int ldqk, const wa_f16 * __restrict__ vt, int ldvt, int T,
+__global__ __launch_bounds__(512) void k_enc_attn(const wa_f16 * __restrict__ qk, int ldqk, const wa_f16 * __restrict__ vt, int ldvt, int T,
                                                   int d, int n_head, float scale, wa_f16 * __restrict__ out, int ldo) {
     // K and V^T tiles (64 rows x 128 B each) arrive by LDS-DMA in a ring of ATT_NST stages, three tiles ahead of the arithmetic; same
     // XOR-swizzled 16-byte slots as k_gemm_f16_dma (LDS-DMA cannot pad rows)
     __shared__ __attribute__((aligned(1024))) wa_f16 KV[ATT_NST][2][64 * 64];
     __shared__ __attribute__((aligned(16))) wa_f16 Ps[4][16 * ATT_LD];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 8 waves: 0-3 own 16 query rows each, 4-7 only issue the LDS-DMA pieces (as in k_gemm_f16_dma: issuing one holds a wave 100+ cycles)
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, wave = wave8 & 3;
+    const bool loader = wave8 >= 4;
     const int fr = lane & 15, fg = lane >> 4, sw = (fr >> 1) & 7;
     // XCD-aware order (workgroup b -> XCD b % 8): an XCD takes a contiguous eighth of the (head, query tile) pairs, head-major, so a
     // head's K / V (384 KB at T = 1500) is streamed into one or two L2s instead of all eight
@@ -700,12 +702,19 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (_Float16) 1.0f;
 
+    if (loader) {
 #pragma unroll
-    for (int p = 0; p < ATT_NST - 1; ++p) ATT_ISSUE(p);
+        for (int p = 0; p < ATT_NST - 1; ++p) ATT_ISSUE(p);
+        for (int kt = 0; kt < n_tiles; ++kt) {
+            // tile kt has landed when at most the (ATT_NST - 2) x 4 loads issued after it are outstanding (every stage issues 4, also past the end)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((ATT_NST - 2) * 4) : "memory");
+            ATT_ISSUE(kt + ATT_NST - 1);    // into the stage read in the previous iteration: every computing wave is past it (barrier)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
+        return;
+    }
     for (int kt = 0; kt < n_tiles; ++kt) {
-        // tile kt has landed when at most the (ATT_NST - 2) x 4 loads issued after it are outstanding (every stage issues 4, also past the end)
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((ATT_NST - 2) * 4) : "memory");
-        ATT_ISSUE(kt + ATT_NST - 1);        // into the stage read in the previous iteration: every wave is past it (barrier)
+        asm volatile("s_barrier" ::: "memory");          // the loader waves have seen tile kt land
         const wa_f16 * Ks = KV[kt % ATT_NST][0], * Vs = KV[kt % ATT_NST][1];
         f32x4 s[4];         // raw dot products; the soft-max runs in base 2 on s * c2
 #pragma unroll
@@ -769,7 +778,6 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
             l_acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ones, l_acc, 0, 0, 0);      // row sums of the F16 probabilities, on the matrix pipe
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
 #undef ATT_ISSUE
     float inv_l[4];
 #pragma unroll
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(256) void k_enc_attn(const wa_f16 * __restrict__ qk
 void wa_launch_enc_attn(hipStream_t stream, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
                         wa_f16 * out, int ldo) {
     const int grid = ((((T + 63) / 64) * n_head + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_enc_attn, dim3(grid), dim3(256), 0, stream, qk, ldqk, vt, ldvt, T, d, n_head, scale, out, ldo);
+    hipLaunchKernelGGL(k_enc_attn, dim3(grid), dim3(512), 0, stream, qk, ldqk, vt, ldvt, T, d, n_head, scale, out, ldo);
 }
 
 // =================================================================================================
