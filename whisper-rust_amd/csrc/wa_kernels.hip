@@ -122,23 +122,23 @@ __global__ __launch_bounds__(256) void k_gemm_f16(const wa_f16 * __restrict__ A,
 typedef __attribute__((address_space(1))) const void g2_gptr;
 typedef __attribute__((address_space(3))) void g2_lptr;
 
-template <int EPI, int BT, int NST>
-__global__ __launch_bounds__(512) void k_gemm_f16_dma(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
+template <int EPI, int BT, int NST, int NL>
+__global__ __launch_bounds__(256 + 64 * NL) void k_gemm_f16_dma(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
                                                       int M, int N, int K, wa_epi e) {
     constexpr int TW = BT / 32;             // 16x16 tiles per MFMA wave and dimension
-    constexpr int LPO = BT / 32;            // DMA wave-instructions (8 rows each) per loader wave, operand and stage
+    constexpr int LPO = BT / 8 / NL;        // DMA wave-instructions (8 rows each) per loader wave, operand and stage (NL loader waves)
     constexpr bool RES = EPI == WA_EPI_RESID || EPI == WA_EPI_CONV2;       // epilogues with a per-element operand
     static_assert(BT == 64 || !RES, "the 128-tile form keeps only per-column epilogue operands in registers");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     wa_f16 (*S)[2][BT * G2_BK] = (wa_f16 (*)[2][BT * G2_BK]) smem_raw;      // [NST][2][BT x 64]
 
-    // 8 waves: 0-3 multiply (2 x 2 grid of wave tiles), 4-7 only issue the LDS-DMA loads.  Issuing a 1 KiB piece holds a wave for
+    // 4 + NL waves: 0-3 multiply (2 x 2 grid of wave tiles), the other NL only issue the LDS-DMA loads.  Issuing a 1 KiB piece holds a wave for
     // 100-185 cycles (measured here: 2048 cycles per k-step of a 128-tile when the MFMA waves issued their own 8 pieces, 512 of them
     // MFMA), so the loads get waves of their own and the two kinds of issue overlap on each SIMD.
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
     const bool loader = wave8 >= 4;
-    const int wave = wave8 & 3;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wave = loader ? wave8 - 4 : wave8;        // index among the multiplying / the loading waves
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
     // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8), each with its own 4 MB L2: XCD x takes a
     // contiguous eighth of the tiles, cut along the longer of M and N, so it streams the smaller operand's panel once and only its own
     // eighth of the other (TCC hit rate 91 % on the encoder's products, profiles/).
@@ -258,14 +258,14 @@ __global__ __launch_bounds__(512) void k_gemm_f16_dma(const wa_f16 * __restrict_
         }
 }
 
-template <int BT, int NST>
+template <int BT, int NST, int NL>
 static void gemm_dma_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
     const int grid = ((((M + BT - 1) / BT) * ((N + BT - 1) / BT) + 7) / 8) * 8;        // a multiple of the 8 XCDs (see the tile order in the kernel)
     constexpr int lds = NST * 2 * BT * G2_BK * 2;
 #define WA_GEMM_CASE(E) case E: { \
         static bool attr_done = false; \
-        if (!attr_done && lds > 64 * 1024) { (void) hipFuncSetAttribute((const void *) k_gemm_f16_dma<E, BT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
-        hipLaunchKernelGGL((k_gemm_f16_dma<E, BT, NST>), dim3(grid), dim3(512), lds, s, A, lda, W, ldw, M, N, K, e); } break;
+        if (!attr_done && lds > 64 * 1024) { (void) hipFuncSetAttribute((const void *) k_gemm_f16_dma<E, BT, NST, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; } \
+        hipLaunchKernelGGL((k_gemm_f16_dma<E, BT, NST, NL>), dim3(grid), dim3(256 + 64 * NL), lds, s, A, lda, W, ldw, M, N, K, e); } break;
     switch (mode) {
         WA_GEMM_CASE(WA_EPI_F16)
         WA_GEMM_CASE(WA_EPI_ENC_QKV)
@@ -312,8 +312,10 @@ void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int 
         // WHISPER_AMD_GEMM_128=1 selects them for products without a per-element epilogue operand.
         static const bool big_tiles = getenv("WHISPER_AMD_GEMM_128") != nullptr;
         const bool res = mode == WA_EPI_RESID || mode == WA_EPI_CONV2;
-        if (big_tiles && !res && big >= 200) gemm_dma_dispatch<128, 3>(stream, mode, A, lda, W, ldw, M, N, K, e);
-        else                                 gemm_dma_dispatch<64, 4>(stream, mode, A, lda, W, ldw, M, N, K, e);
+        // (4 loader waves: 8 of them - 2 pieces each - measured the same 1.50 ms per encoder pass: the CU's LDS-DMA intake is the limit,
+        //  not the issue rate of a wave)
+        if (big_tiles && !res && big >= 200) gemm_dma_dispatch<128, 3, 4>(stream, mode, A, lda, W, ldw, M, N, K, e);
+        else                                 gemm_dma_dispatch<64, 4, 4>(stream, mode, A, lda, W, ldw, M, N, K, e);
         return;
     }
     static const long thr = getenv("WHISPER_AMD_GEMM_THR") ? atol(getenv("WHISPER_AMD_GEMM_THR")) : 1000000;   // measured on ggml-small shapes (M = 1500): 64x64 tiles (>= 4 blocks per CU) beat 128x128 on every GEMM of the encoder
