@@ -222,16 +222,17 @@ __device__ __forceinline__ float wa_expf_libm(float x) {
 // F64 results can differ by at most delta = 2 n u sum|x| (u = 2^-53).  Rounding to F32 after the division is
 // monotonic, so when (S - delta)/n and (S + delta)/n round to the SAME float, that float is the reference's
 // value whatever its order was.  Otherwise (probability ~ n 2^-27 per row) one lane redoes the sum in index order.
-__device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out) {
+// `rn` = 1.0 / (double) n, which a caller on a latency-critical path brings along (an F64 division is ~150 dependent cycles).
+__device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out, double rn) {
     // conservative bounds of (S -+ delta)/n by multiplication (1/n in F64 is within 2^-53; the 2^-48 slack covers it):
     // if both bounds round to the same float, the correctly rounded quotient of any sum in the interval does too.
-    const double rn = 1.0 / (double) n;
     const double delta = (2.0 * (double) n * 0x1p-53 * A + fabs(S) * 0x1p-48) * rn * 1.000001;
     const double q = S * rn;
     const float lo = (float) (q - delta), hi = (float) (q + delta);
     out = lo;
     return lo == hi;
 }
+__device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out) { return wa_sum_certain(S, A, n, out, 1.0 / (double) n); }
 
 // In-order F64 sum of an LDS-resident row by one lane (the certificate's fallback): b128 reads pipeline, the 8-cycle
 // dependent F64 adds are all that is left (~3 us for 768 elements; the same loop over global memory took ~60 us).

@@ -20,6 +20,7 @@ struct wa_mega_layer {          // device-resident table, one entry per decoder 
 struct wa_mega_args {
     // model
     const wa_mega_layer * layers; int n_layer, d, n_head, n_vocab; float eps;
+    double rn_d;                                                                // 1.0 / (double) d (LayerNorm: keeps an F64 division off every phase)
     const wa_f16 * te; const float * pe; const float * lnf_w, * lnf_b; const wa_f16 * gelu;
     // state
     wa_f16 * kv_k, * kv_v; unsigned long long kv_layer_stride;                  // self K/V [layer][cell][d]

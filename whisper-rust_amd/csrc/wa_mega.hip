@@ -154,7 +154,7 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
     if (q >= 0) {
         double s = ((lnred[0] + lnred[1]) + (lnred[2] + lnred[3])) + (lnred[4] + lnred[5]);
         const double a = ((lnred[6] + lnred[7]) + (lnred[8] + lnred[9])) + (lnred[10] + lnred[11]);
-        if (!wa_sum_certain(s, a, d, mean)) {
+        if (!wa_sum_certain(s, a, d, mean, A->rn_d)) {
             if (lane == 0) s = wa_seq_sum_lds(xf, d, false, 0.0f);
             s = __shfl(s, 0, WAVE);
             mean = (float) (s / (double) d);
@@ -169,7 +169,7 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
     if (q >= 0) {
         double s2 = ((lnred[12] + lnred[13]) + (lnred[14] + lnred[15])) + (lnred[16] + lnred[17]);
         float variance;
-        if (!wa_sum_certain(s2, s2, d, variance)) {
+        if (!wa_sum_certain(s2, s2, d, variance, A->rn_d)) {
             if (lane == 0) s2 = wa_seq_sum_lds(xf, d, true, mean);
             s2 = __shfl(s2, 0, WAVE);
             variance = (float) (s2 / (double) d);
