@@ -48,6 +48,38 @@ __device__ __forceinline__ void gr_store(gu64 * g, unsigned seq, unsigned v) {
     __hip_atomic_store(g, ((u64) seq << 32) | (u64) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 gr_load(gu64 * g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A granule whose readers all sit on the WRITER'S XCD (`local`, established at run time: mg_role_cross): a plain store keeps the line
+// in that XCD's L2, where the readers' L1-bypassing polls find it - an sc1 store drops it from L2 and every reader goes out to the
+// fabric (MI355X_MICROARCH.md, inter-workgroup visibility).  Never for a granule that another XCD reads: its L2 would stay stale.
+__device__ __forceinline__ void gr_store_l(gu64 * g, unsigned seq, unsigned v, bool local) {
+    if (local) __hip_atomic_store(g, ((u64) seq << 32) | (u64) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else       __hip_atomic_store(g, ((u64) seq << 32) | (u64) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Role of workgroup b of n (role 0: weight streaming, index = its rank; 1: self-attention of head index; 2: cross-attention, index =
+// 4 head + quarter).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one - observed, not promised: the
+// cross-attention role checks it at run time), so with n % 8 == 0 the four quarters of a head are placed 8 apart: their three
+// exchanges per layer then stay inside one L2.  Heads sit in groups of 8 at the top of the grid; the slots of a group that
+// has fewer than 8 heads go to self-attention first, then to weight streaming.
+__device__ __forceinline__ void mg_role_of(int n, int H, int b, int & role, int & idx) {
+    const int G8 = (H + 7) >> 3, top = n - 32 * G8;
+    const int R = H - 8 * (G8 - 1);                     // heads in the last group (1..8)
+    const int F = 4 * (8 - R);                          // free slots up there
+    const int s_low = H > F ? H - F : 0;                // self-attention heads placed below `top`
+    if ((n & 7) != 0 || top - s_low < 1) {              // plain layout
+        const int nG = n - 5 * H;
+        if (b < nG) { role = 0; idx = b; } else if (b < nG + H) { role = 1; idx = b - nG; } else { role = 2; idx = b - nG - H; }
+        return;
+    }
+    if (b >= top) {
+        const int t = b - top, r = t & 7, k = t >> 3, q = k >> 2, w = k & 3, h = r + 8 * q;
+        if (h < H) { role = 2; idx = 4 * h + w; return; }
+        const int f = (r - R) + (8 - R) * w;            // free slot number
+        if (f < H) { role = 1; idx = f; } else { role = 0; idx = (top - s_low) + (f - H); }
+        return;
+    }
+    if (b >= top - s_low) { role = 1; idx = F + (b - (top - s_low)); } else { role = 0; idx = b; }
+}
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xf, 0xf, true); }
 
@@ -494,12 +526,12 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
 // Every wave loads the weights of its NEXT task right after finishing the current one.
 // -------------------------------------------------------------------------------------------------
 template <int NP3, int NS>
-__device__ __noinline__ void mg_role_gemv(mg_kargs A_) {
+__device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wg = blockIdx.x, nG = (int) gridDim.x - 5 * A->n_head;
+    const int wg = __builtin_amdgcn_readfirstlane(idx_), nG = (int) gridDim.x - 5 * A->n_head;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
     unsigned pf[96];
     bool have_pf = false;
@@ -752,12 +784,12 @@ __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 
 // role: self-attention of head h (whisper.cpp:2636-2651), every layer.  The K/V cells of earlier tokens are copied
 // into LDS while the GEMV workgroups are busy with the previous phases; the new cell arrives with the query.
 // -------------------------------------------------------------------------------------------------
-__device__ __noinline__ void mg_role_self(mg_kargs A_) {
+__device__ __noinline__ void mg_role_self(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = (int) blockIdx.x - ((int) gridDim.x - 5 * A->n_head);
+    const int h = __builtin_amdgcn_readfirstlane(idx_);
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
 
     wa_f16 * Ks = (wa_f16 *) smem;                                  // [512][64]
@@ -884,15 +916,16 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_) {
 #define MG_CGR 2048                                     // granules per (layer, head) of the cross exchange area
 #define MG_CGR_MAX 0
 #define MG_CGR_SUM 8
+#define MG_CGR_XCC 16                                   // (layer 0 area only) the four workgroups' XCC_IDs
 #define MG_CGR_PART 64                                  // + (w - 1) * 576: 512 chain sums + 8 leftover probabilities
 
-__device__ __noinline__ void mg_role_cross(mg_kargs A_) {
+__device__ __noinline__ void mg_role_cross(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = A->n_head;
-    const int ci = (int) blockIdx.x - ((int) gridDim.x - 4 * H);
+    const int ci = __builtin_amdgcn_readfirstlane(idx_);
     const int h = ci >> 2, w = ci & 3;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
     const unsigned seq = c.seq;
@@ -913,6 +946,19 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
     const int a = tid & 3, ks = tid >> 2;
     const int np = T & ~31, nsteps = np >> 5, nl = T - np, n8 = T & ~7, ng = n8 >> 3;
     if (wave == 0) mg_pick(A, lane, (int *) (smem + MG_PICK_OFF));
+    // Do the head's four workgroups share an XCD (mg_role_of places them 8 apart, which is where the dispatcher has been observed to put
+    // them - not a promise)?  Each publishes its XCC_ID, all read the four; only then do the exchanges among them use L2-resident stores.
+    if (wave == 0) {
+        const unsigned xcc = (unsigned) __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;        // HW_REG_XCC_ID[3:0]
+        gu64 * X0 = (gu64 *) A->cross_gr + (size_t) h * MG_CGR + MG_CGR_XCC;
+        if (lane == 0) gr_store(X0 + w, seq, xcc);
+        unsigned v[1];
+        mg_sweep<1>(X0, [&](int) { return lane < 4 ? lane : -1; }, c, lane, v, 2900u);
+        const bool same = lane >= 4 || v[0] == xcc;
+        if (lane == 0) bc[2] = __builtin_amdgcn_ballot_w64(same) == ~0ull && !c.dead ? 1.0f : 0.0f;
+    }
+    mg_barrier();
+    const bool local = bc[2] != 0.0f;
     for (int l = 0; l < L; ++l) {
         gu64 * X = (gu64 *) A->cross_gr + ((size_t) l * H + h) * MG_CGR;
         const gch kp = (gch) A->cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
@@ -959,7 +1005,7 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
             float m = red[0];
 #pragma unroll
             for (int k = 1; k < MG_NW; ++k) m = fmaxf(m, red[k]);
-            if (lane == 0) gr_store(X + MG_CGR_MAX + w, seq, __float_as_uint(m));
+            if (lane == 0) gr_store_l(X + MG_CGR_MAX + w, seq, __float_as_uint(m), local);
             unsigned v[1];
             mg_sweep<1>(X + MG_CGR_MAX, [&](int) { return lane < 4 ? lane : -1; }, c, lane, v, 2100u + l);
             float g = lane < 4 ? __uint_as_float(v[0]) : -INFINITY;
@@ -989,7 +1035,7 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
         if (wave == 0) {        // (2) partial sums -> total, certified
             const double ps = ((redd[0] + redd[1]) + (redd[2] + redd[3])) + ((redd[4] + redd[5]) + (redd[6] + redd[7]));
             const u64 pb = (u64) __double_as_longlong(ps);
-            if (lane == 0) { gr_store(X + MG_CGR_SUM + 2 * w, seq, (unsigned) pb); gr_store(X + MG_CGR_SUM + 2 * w + 1, seq, (unsigned) (pb >> 32)); }
+            if (lane == 0) { gr_store_l(X + MG_CGR_SUM + 2 * w, seq, (unsigned) pb, local); gr_store_l(X + MG_CGR_SUM + 2 * w + 1, seq, (unsigned) (pb >> 32), local); }
             unsigned v[1];
             mg_sweep<1>(X + MG_CGR_SUM, [&](int) { return lane < 8 ? lane : -1; }, c, lane, v, 2200u + l);
             double tot = 0.0;
@@ -1011,7 +1057,7 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
             if (cc < T) {
                 const wa_f16 ph = f2h(sc[tid] * inv);
                 p16[(tid & 7) * MG_CSTEPS + (tid >> 3)] = ph;         // by chain: the P V wave reads its 48 probabilities as 6 x 16 bytes
-                if (cc >= np) { if (w == 0) pleft[cc - np] = ph; else gr_store(X + MG_CGR_PART + (w - 1) * 576 + 512 + (tid & 7), seq, (unsigned) ph); }
+                if (cc >= np) { if (w == 0) pleft[cc - np] = ph; else gr_store_l(X + MG_CGR_PART + (w - 1) * 576 + 512 + (tid & 7), seq, (unsigned) ph, local); }
             }
         }
         mg_barrier();
@@ -1024,7 +1070,7 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
 #pragma unroll
             for (int s = 0; s < MG_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(vv[s]), (float) pw[s >> 3][s & 7], acc);
             if (w == 0) part[wave * 64 + lane] = acc;
-            else gr_store(X + MG_CGR_PART + (w - 1) * 576 + wave * 64 + lane, seq, __float_as_uint(acc));
+            else gr_store_l(X + MG_CGR_PART + (w - 1) * 576 + wave * 64 + lane, seq, __float_as_uint(acc), local);
         }
         mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 6, mg_now());
         if (w == 0) {           // (3) gather the other three workgroups' chain sums and leftover probabilities, finish the head
@@ -1052,12 +1098,12 @@ __device__ __noinline__ void mg_role_cross(mg_kargs A_) {
 }
 
 __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A) {
-    const int nG = (int) gridDim.x - 5 * A.n_head;       // H self-attention + 4 H cross-attention workgroups
-    const int wg = blockIdx.x;
+    int role, idx;                                       // H self-attention + 4 H cross-attention workgroups, the rest stream weights
+    mg_role_of((int) gridDim.x, A.n_head, (int) blockIdx.x, role, idx);
     const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();     // = &A (the struct is the only argument)
-    if (wg < nG) { if (A.d == 768) mg_role_gemv<2, 24>(Ap); else if (A.d < 768) mg_role_gemv<2, 0>(Ap); else mg_role_gemv<MG_NP3, 0>(Ap); }
-    else if (wg < nG + A.n_head) mg_role_self(Ap);
-    else                         mg_role_cross(Ap);
+    if (role == 0) { if (A.d == 768) mg_role_gemv<2, 24>(Ap, idx); else if (A.d < 768) mg_role_gemv<2, 0>(Ap, idx); else mg_role_gemv<MG_NP3, 0>(Ap, idx); }
+    else if (role == 1) mg_role_self(Ap, idx);
+    else                mg_role_cross(Ap, idx);
 }
 
 size_t wa_mega_lds_bytes() {
