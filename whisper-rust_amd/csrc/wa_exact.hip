@@ -194,6 +194,7 @@ struct wa_ln_in { const float * x = nullptr; int ldx = 0; const float * w = null
 #define GEMV_BATCH 24      // weight loads kept in flight per lane (8 B each)
 #define GEMV_THREADS 256   // 4 waves = 32 weight rows per block iteration
 #define GEMV_LN_NPL 8      // LayerNorm elements per thread (K <= 2048)
+#define GEMV_WLN_NPL 20    // LayerNorm elements per lane of the wave-per-row form (K <= 1280)
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
                                                              const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
     extern __shared__ __attribute__((aligned(16))) wa_f16 xs[];   // [MT][K]
     __shared__ double red[16];
-    __shared__ __attribute__((aligned(16))) float lrow[GEMV_THREADS * GEMV_LN_NPL];
+    __shared__ __attribute__((aligned(16))) float lrow[4 * 64 * GEMV_WLN_NPL];      // (>= GEMV_THREADS * GEMV_LN_NPL)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = lane & 7, slot = lane >> 3;
     const int nsteps = K >> 5;
@@ -279,7 +280,31 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
         load_batch(W + (size_t) nn * ldw + 4 * u, 0);
     }
 
-    if (ln.x) {
+    if (ln.x && MT > 1 && M > 1 && K <= 64 * GEMV_WLN_NPL) {
+        // several rows (beam / multi-decoder steps): one wave per row, rows in parallel (the block-wide form below spends two block
+        // reductions per row, one row after the other: 8-10 us of a 17 us launch at 5 rows)
+        for (int m = wave; m < M; m += GEMV_THREADS / 64) {
+            const int src = rows ? rows[m] : m;
+            float xv[GEMV_WLN_NPL], gw[GEMV_WLN_NPL], gb[GEMV_WLN_NPL], mean, scale;
+#pragma unroll
+            for (int k = 0; k < GEMV_WLN_NPL; ++k) { const int i = lane + 64 * k, ic = i < K ? i : K - 1; gw[k] = ln.w[ic]; gb[k] = ln.b[ic]; }
+            wa_ln_stats<GEMV_WLN_NPL>(ln.x + (size_t) src * ln.ldx, K, ln.eps, lane, lrow + (size_t) wave * 64 * GEMV_WLN_NPL, xv, mean, scale);
+#pragma unroll
+            for (int k = 0; k < GEMV_WLN_NPL; ++k) {
+                const int i = lane + 64 * k;
+                if (i < K) {
+                    float y = xv[k] - mean;
+                    y = y * scale;
+                    y = y * gw[k];
+                    y = y + gb[k];
+                    xs[(size_t) m * K + i] = f2h(y);
+                }
+            }
+        }
+        for (int m = M; m < MT; ++m)
+            for (int i = tid; i < K; i += GEMV_THREADS) xs[(size_t) m * K + i] = 0;
+        __syncthreads();
+    } else if (ln.x) {
         for (int m = 0; m < MT; ++m) {
             if (m < M) {
                 const int src = rows ? rows[m] : m;
