@@ -263,6 +263,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int u = lane & 7, slot = lane >> 3;
     const int nsteps = K >> 5;
+    const int nthr = blockDim.x, rpb = 8 * (nthr >> 6);      // 256 threads = 32 rows per block iteration; 64 = 8 (narrow products: more blocks)
 
     // The weights do not depend on the previous kernel's output: issue the first batch of loads BEFORE staging the
     // activations, so the HBM round trip overlaps the LayerNorm / copy prologue instead of following it.
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
         }
     };
     {
-        const int n = blockIdx.x * 32 + wave * 8 + slot;
+        const int n = blockIdx.x * rpb + wave * 8 + slot;
         const int nn = n < N ? n : N - 1;
         load_batch(W + (size_t) nn * ldw + 4 * u, 0);
     }
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
         }
     } else {
         const int kc = K >> 3;
-        for (int c = tid; c < MT * kc; c += GEMV_THREADS) {
+        for (int c = tid; c < MT * kc; c += nthr) {
             const int m = c / kc, cc = c - m * kc;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (m < M) { const int src = rows ? rows[m] : m; v = *(const uint4 *) (A + (size_t) src * lda + cc * 8); }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
     }
     __syncthreads();
     bool first = true;
-    for (int nb = blockIdx.x * 32; nb < N; nb += gridDim.x * 32) {
+    for (int nb = blockIdx.x * rpb; nb < N; nb += gridDim.x * rpb) {
         const int n = nb + wave * 8 + slot;
         const int nn = n < N ? n : N - 1;
         const wa_f16 * wrow = W + (size_t) nn * ldw + 4 * u;
@@ -377,12 +378,16 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
 template <int MT>
 static void gemv_exact_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_ln_in & ln,
                                 const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
-    int grid = (N + 31) / 32;
+    // single-row products with few output rows and no LayerNorm prologue (the three into the residual stream: N = d) run one wave per
+    // block: 4 x the blocks (N / 8 instead of N / 32 - 24 blocks for d = 768 left 232 CUs idle).  Not for several rows: staging MT x K
+    // activations per 8 weight rows with 64 threads costs more than the extra blocks give (5-row step 1.23 -> 1.34 ms).
+    const int nthr = (MT == 1 && !ln.x && N <= 2048) ? 64 : GEMV_THREADS, rpb = 8 * (nthr / 64);
+    int grid = (N + rpb - 1) / rpb;
     if (grid > 4096) grid = 4096;
     const size_t lds = (size_t) MT * K * sizeof(wa_f16);
 #define WA_CASE(E) case E: { \
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_gemv_exact<MT, E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); \
-        hipLaunchKernelGGL((k_gemv_exact<MT, E>), dim3(grid), dim3(GEMV_THREADS), lds, s, A, lda, rows, ln, W, ldw, M, N, K, e); } break;
+        hipLaunchKernelGGL((k_gemv_exact<MT, E>), dim3(grid), dim3(nthr), lds, s, A, lda, rows, ln, W, ldw, M, N, K, e); } break;
     switch (mode) {
         WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_GELU_F16) WA_CASE(WA_EPI_RESID) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_DEC_QKV)
         default: break;
@@ -395,6 +400,7 @@ static void gemv_exact_any(hipStream_t stream, wa_epi_mode mode, const wa_f16 * 
     if (M <= 1)      gemv_exact_dispatch<1>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
     else if (M <= 2) gemv_exact_dispatch<2>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
     else if (M <= 4) gemv_exact_dispatch<4>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
+    else if (M <= 5) gemv_exact_dispatch<5>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);      // beam_size / best_of default to 5
     else             gemv_exact_dispatch<8>(stream, mode, A, lda, rows, ln, W, ldw, M, N, K, e);
 }
 
