@@ -315,12 +315,23 @@ __global__ __launch_bounds__(GEMV_THREADS) void k_gemv_exact(const wa_f16 * __re
             }
         }
     } else {
-        const int kc = K >> 3;
-        for (int c = tid; c < MT * kc; c += nthr) {
-            const int m = c / kc, cc = c - m * kc;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (m < M) { const int src = rows ? rows[m] : m; v = *(const uint4 *) (A + (size_t) src * lda + cc * 8); }
-            *(uint4 *) (&xs[(size_t) m * K + cc * 8]) = v;
+        // 8 chunks of 16 bytes per thread and round, all loads of a round in flight together (unconditional, clamped: a predicated load
+        // makes the compiler wait for every outstanding one - the K = 4d product then spent 7 serial round trips here)
+        typedef unsigned stg_u4 __attribute__((ext_vector_type(4)));
+        const int kc = K >> 3, total = MT * kc;
+        for (int c0 = 0; c0 < total; c0 += 8 * nthr) {
+            stg_u4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = min(c0 + tid + j * nthr, total - 1), m = c / kc, cc = c - m * kc;
+                const int src = rows ? rows[min(m, M - 1)] : min(m, M - 1);
+                v[j] = *(const stg_u4 *) (A + (size_t) src * lda + cc * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + tid + j * nthr;
+                if (c < total) { const int m = c / kc; *(stg_u4 *) (&xs[(size_t) c * 8]) = m < M ? v[j] : (stg_u4) (0u); }
+            }
         }
     }
     __syncthreads();
