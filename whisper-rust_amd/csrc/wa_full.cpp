@@ -12,6 +12,11 @@
 #include <cstring>
 #include <cstdlib>
 #include <regex>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <immintrin.h>
 
 void wa_dtw_timestamps(whisper_context * ctx, whisper_state * st, const whisper_full_params & params, int i_segment, size_t n_segments,
@@ -267,6 +272,55 @@ bool same_tokens(const wa_sequence & a, const wa_sequence & b) {   // whisper.cp
     return true;
 }
 
+// Host workers for the per-decoder passes of a multi-decoder step (beam search, best_of > 1): the reference spreads them over
+// n_threads (whisper.cpp:7442-7476).  Each decoder's logits rules, its log-soft-max over the vocabulary and its draws touch only that
+// decoder's buffers and its own RNG, so the results do not depend on the schedule.  Lives for one whisper_full call.
+struct wa_pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)> * fn = nullptr;
+    int n_items = 0, next = 0, done = 0;
+    unsigned long gen = 0;
+    bool stop = false;
+
+    explicit wa_pool(int n_workers) {
+        for (int i = 0; i < n_workers; ++i) th.emplace_back([this] { worker(); });
+    }
+    ~wa_pool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (auto & t : th) t.join();
+    }
+    void drain(std::unique_lock<std::mutex> & lk) {        // take items until none is left (lock held on entry and exit)
+        while (next < n_items) {
+            const int i = next++;
+            lk.unlock();
+            (*fn)(i);
+            lk.lock();
+            if (++done == n_items) cv_done.notify_all();
+        }
+    }
+    void worker() {
+        std::unique_lock<std::mutex> lk(m);
+        unsigned long seen = 0;
+        for (;;) {
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            drain(lk);
+        }
+    }
+    void run(int n, const std::function<void(int)> & f) {
+        if (n <= 1 || th.empty()) { for (int i = 0; i < n; ++i) f(i); return; }
+        std::unique_lock<std::mutex> lk(m);
+        fn = &f; n_items = n; next = 0; done = 0; ++gen;
+        cv.notify_all();
+        drain(lk);                                         // the calling thread works too
+        cv_done.wait(lk, [&] { return done == n_items; });
+    }
+};
+
 struct runner {
     whisper_context * ctx;
     whisper_state   * st;
@@ -275,6 +329,12 @@ struct runner {
     const int n_vocab;
     std::vector<int> suppress_ids;      // tokens killed by suppress_regex / suppress_nst, resolved once per call
     int blank_id = -1;
+    std::unique_ptr<wa_pool> pool;      // created with the first multi-decoder step
+    void par_for(int n, const std::function<void(int)> & f) {
+        // one thread per decoder (up to 8): n_threads is sized for a CPU engine's matrix products, which this backend does not run
+        if (n > 1 && !pool) pool.reset(new wa_pool(std::min(n, 8) - 1));
+        if (pool) pool->run(n, f); else for (int i = 0; i < n; ++i) f(i);
+    }
 
     runner(whisper_context * c, whisper_state * s, const whisper_full_params & params)
         : ctx(c), st(s), p(params), vocab(c->vocab), n_vocab(c->vocab.n_vocab) {}
@@ -649,9 +709,9 @@ int runner::run(const float * samples, int n_samples) {
                 if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) for (auto & bc : bc_per_dec) bc.clear();
 
                 // ---- sample one token per live decoder (whisper.cpp:7169-7227) ----
-                for (int j = 0; j < n_dec; ++j) {
+                par_for(n_dec, [&](int j) {         // (each decoder: its own probabilities, RNG, sequence and candidate list)
                     auto & dec = st->decoders[j];
-                    if (dec.completed || dec.failed) continue;
+                    if (dec.completed || dec.failed) return;
                     if (p.strategy == WHISPER_SAMPLING_GREEDY) {
                         dec.sequence.tokens.push_back(sample_token(dec, t_cur < 1e-6f));
                         dec.sequence.sum_logprobs_all += dec.sequence.tokens.back().plog;
@@ -662,7 +722,7 @@ int runner::run(const float * samples, int n_samples) {
                             bc_per_dec[j].back().sequence.sum_logprobs_all += tok.plog;
                         }
                     }
-                }
+                });
                 beam_candidates.clear();
                 for (const auto & bc : bc_per_dec) {
                     beam_candidates.insert(beam_candidates.end(), bc.begin(), bc.end());
@@ -779,11 +839,11 @@ int runner::run(const float * samples, int n_samples) {
                     }
                     if (!have_logits && !wa_decode(*ctx, *st, b, false, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -9; }
                     const int64_t ts1 = wa_time_us();
-                    for (int j = 0; j < n_dec; ++j) {
+                    par_for(n_dec, [&](int j) {
                         auto & dec = st->decoders[j];
-                        if (dec.failed || dec.completed) continue;
+                        if (dec.failed || dec.completed) return;
                         process_logits(dec, t_cur, need_full_probs);
-                    }
+                    });
                     st->t_sample_us += wa_time_us() - ts1;
                 }
             }
