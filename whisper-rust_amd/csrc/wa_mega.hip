@@ -535,6 +535,7 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
     unsigned pf[96];
     bool have_pf = false;
+    constexpr bool BIG = NS == 0 && NP3 == MG_NP3;       // d > 768: more row groups per workgroup than prefetching waves - the idle waves assist
 
     float  * xf  = (float *) smem;                               // [d]   residual row (F32)
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);        // [4d]  GEMV input (F16)
@@ -572,10 +573,15 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         // ---------------- P1: LayerNorm + q|k|v ----------------
         mg_ln3<NP3>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
         mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, mg_slot(wave, MG_EX_P4), lane);
-        if (wave == 1 || wave == 2) {
+        // (Wide models give a workgroup more row groups than the one per wave that is prefetched.  The waves idle in a phase then
+        //  assist: they take the extra groups on demand - overwriting the rows they hold for a later phase - and fetch those again
+        //  afterwards, long before that phase.  ggml-small and below: one group per wave, nothing changes.)
+        if (wave == 1 || wave == 2 || (BIG && (wave == 3 || wave == 4))) {
+            const bool own = !BIG || wave <= 2;
+            bool assisted = false;
             gu64 * eq = mg_edge(A, l, E_QKV);
-            for (int grp = wave - 1; grp < g_qkv; grp += 2) {
-                if (grp >= 2) t = mg_task8<NS>(pf, Y.qkv_w, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane);
+            for (int grp = wave - 1; grp < g_qkv; grp += BIG ? 4 : 2) {
+                if (grp >= 2) { t = mg_task8<NS>(pf, Y.qkv_w, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane); assisted = true; }
                 float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 v = v * t.scale;
@@ -587,7 +593,9 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 }
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 0) * 8 + 3, mg_now());
-            t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+            if (own) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+            else if (assisted) t = wave == 3 ? mg_task8<NS>(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, 0, lane)
+                                             : mg_task8<NS>(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P3: self-attention out-projection + residual ----------------
         {
@@ -595,31 +603,38 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
         }
         mg_barrier();
-        if (wave == 3) {
+        if (wave == 3 || (BIG && wave == 5)) {        // wave 5 assists (it holds this layer's FC2 rows, next needed in P8)
+            const bool own = !BIG || wave == 3;
+            bool assisted = false;
             gu64 * ex = mg_edge(A, l, E_X1);
-            for (int grp = 0; grp < g_d8; ++grp) {
-                if (grp >= 1) t = mg_task8<NS>(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane);
+            for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
+                if (grp >= 1) { t = mg_task8<NS>(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
                 float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
-            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 1) * 8 + 3, mg_now());
-            t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+            mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 1) * 8 + 3, mg_now());
+            if (own) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else if (assisted) t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
         mg_ln3<NP3>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
         mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, mg_slot(wave, MG_EX_P7), lane);
-        if (wave == 4) {
+        if (wave == 4 || (BIG && wave == 3)) {        // wave 3 assists (it holds this layer's cross-attention output rows, next needed in P6)
+            const bool own = !BIG || wave == 4;
+            bool assisted = false;
             gu64 * eq = mg_edge(A, l, E_QC);
-            for (int grp = 0; grp < g_d8; ++grp) {
-                if (grp >= 1) t = mg_task8<NS>(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane);
+            for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
+                if (grp >= 1) { t = mg_task8<NS>(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
                 float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
-            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
-            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
+            if (own) {
+                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            } else if (assisted) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P6: cross-attention out-projection + residual ----------------
         {
@@ -627,27 +642,36 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
         }
         mg_barrier();
-        if (wave == 3) {
+        if (wave == 3 || (BIG && wave == 4)) {        // wave 4 assists (it holds the next layer's cross-query rows)
+            const bool own = !BIG || wave == 3;
+            bool assisted = false;
             gu64 * ex = mg_edge(A, l, E_X2);
-            for (int grp = 0; grp < g_d8; ++grp) {
-                if (grp >= 1) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane);
+            for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
+                if (grp >= 1) { t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
                 float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
-            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
-            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
+            if (own) {
+                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            } else if (assisted) {
+                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            }
         }
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
         if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
         mg_ln3<NP3>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
         if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
         else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, mg_slot(wave, MG_EX_FINAL), lane);
-        if (wave == 1 || wave == 2) {
+        if (wave == 1 || wave == 2 || (BIG && (wave == 3 || wave == 4))) {        // waves 3, 4 assist (they hold the next layer's out-projection / cross-query rows)
+            const bool own = !BIG || wave <= 2;
+            bool assisted = false;
             gu64 * eh = mg_edge(A, l, E_HF);
-            for (int grp = wave - 1; grp < g_ff; grp += 2) {
-                if (grp >= 2) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane);
+            for (int grp = wave - 1; grp < g_ff; grp += BIG ? 4 : 2) {
+                if (grp >= 2) { t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane); assisted = true; }
                 float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
                 v = v + t.bias;
                 float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
@@ -655,8 +679,14 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
-            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            if (own) {
+                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            } else if (assisted) {
+                if (l + 1 >= L) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+                else t = wave == 3 ? mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane)
+                                   : mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+            }
         }
         // ---------------- P8: FC2 + residual ----------------
         {   // the widest hand-off (2d granules)
@@ -664,17 +694,25 @@ __device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
         mg_barrier();
-        if (wave == 5) {
+        if (wave == 5 || (BIG && (wave == 3 || wave == 4))) {        // waves 3, 4 assist (as in P7)
+            const bool own = !BIG || wave == 5;
+            bool assisted = false;
             gu64 * ex = mg_edge(A, l, E_X3);
-            for (int grp = 0; grp < g_d16; ++grp) {
-                if (grp >= 1) t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, grp, lane);
+            for (int grp = own ? 0 : wave - 2; grp < g_d16; grp += BIG ? 3 : 1) {
+                if (grp >= 1) { t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, grp, lane); assisted = true; }
                 float v = mg_dot16<4 * NS>(pf, t.wrow, t.valid, d4 >> 5, xin, lane & 15, true);
                 v = v + t.bias;
                 if (t.valid && (lane & 15) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
-            mg_trace(A, wg == 0 && lane == 0, (l * 8 + 5) * 8 + 3, mg_now());
-            if (l + 1 < L) t = mg_task16<4 * NS>(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
-            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 5) * 8 + 3, mg_now());
+            if (own) {
+                if (l + 1 < L) t = mg_task16<4 * NS>(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            } else if (assisted) {
+                if (l + 1 >= L) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+                else t = wave == 3 ? mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane)
+                                   : mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+            }
         }
     }
     if (L == 0 && wave >= 1 && wave <= 5) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
