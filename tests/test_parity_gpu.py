@@ -285,7 +285,7 @@ def test_small_shape_properties(wrs, amd_lib):
     st.free(); ctx.free()
 
 
-@pytest.mark.parametrize("name,n_tok", [("s128", 40), ("tiny", 24), ("base", 24), ("small", 48)])
+@pytest.mark.parametrize("name,n_tok", [("s128", 40), ("tiny", 24), ("base", 24), ("small", 48), ("w1280", 12)])
 def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok, monkeypatch):
     """The single-token decoder pass as ONE persistent launch (wa_mega.hip) against the launch sequence (which the tests
     above pin to the reference): bit-identical logits token by token, over enough tokens that n_kv crosses the n % 8 and
