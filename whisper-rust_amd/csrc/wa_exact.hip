@@ -101,10 +101,87 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact(const wa_f16 * __restrict
         }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same product (same lanes, same 32 partial sums per output, same order) with the operand tiles brought in by LDS-DMA through a
+// ring of 4 stages of 64 k each: the register-staged form above waits out a memory round trip per 32-k step (~1 us against 0.24 us
+// of FMAs).  K % 64 == 0.  XOR-swizzled 16-byte slots as in k_gemm_f16_dma (a thread reads whole rows: the 8 distinct rows of a
+// wave's li / lj land on 8 distinct slots); every wave issues its own two 1 KB pieces per stage (a fifth, loading wave would not fit
+// beside two 240-VGPR workgroups per CU).
+// -------------------------------------------------------------------------------------------------
+#define EXD_NST 4
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_exact_dma(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
+                                                           int M, int N, int K, wa_epi e) {
+    __shared__ __attribute__((aligned(1024))) wa_f16 S[EXD_NST][2][32 * 64];       // 4 x (4 KB + 4 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane >> 3, lj = lane & 7;
+    const int tiles_n = (N + 31) / 32;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+
+    // this wave's piece (8 rows x 128 B) of either operand: rows 8 wave + lane / 8, slot lane % 8 holds k-chunk slot ^ ((row >> 1) & 7)
+    const int prow = 8 * wave + (lane >> 3), pchunk = (lane & 7) ^ ((prow >> 1) & 7);
+    const wa_f16 * ga = A + (size_t) min(m0 + prow, M - 1) * lda + pchunk * 8;
+    const wa_f16 * gw = W + (size_t) min(n0 + prow, N - 1) * ldw + pchunk * 8;
+    const int nk = K >> 6;
+#define EXD_ISSUE(kt_) do { const int k0_ = min((kt_), nk - 1) * 64; const int st_ = (kt_) % EXD_NST; \
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *) (ga + k0_), (__attribute__((address_space(3))) void *) (&S[st_][0][wave * 8 * 64]), 16, 0, 0); \
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void *) (gw + k0_), (__attribute__((address_space(3))) void *) (&S[st_][1][wave * 8 * 64]), 16, 0, 0); } while (0)
+
+    float acc[2][2][32];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[p][q][i] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < EXD_NST - 1; ++p) EXD_ISSUE(p);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed when at most the (EXD_NST - 2) x 2 loads issued after it are outstanding (every stage issues 2, also past the end)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((EXD_NST - 2) * 2) : "memory");
+        EXD_ISSUE(kt + EXD_NST - 1);          // into the stage read in the previous iteration: every wave is past it (barrier)
+        const wa_f16 * As = S[kt % EXD_NST][0], * Ws = S[kt % EXD_NST][1];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {      // two 32-element steps of the reference's loop per stage
+            half8 a[2][4], w[2][4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[p][c] = *(const half8 *) (&As[(wm * 16 + li * 2 + p) * 64 + (((ks * 4 + c) ^ li) * 8)]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w[q][c] = *(const half8 *) (&Ws[(wn * 16 + lj * 2 + q) * 64 + (((ks * 4 + c) ^ lj) * 8)]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            acc[p][q][c * 8 + i] = fmaf((float) w[q][c][i], (float) a[p][c][i], acc[p][q][c * 8 + i]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
+#undef EXD_ISSUE
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = m0 + wm * 16 + li * 2 + p, n = n0 + wn * 16 + lj * 2 + q;
+            if (m < M && n < N) epi_store<EPI>(e, m, n, wa_tree32(acc[p][q]));
+        }
+}
+
 void wa_launch_gemm_exact(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
                           const wa_epi & e) {
     const int grid = ((M + 31) / 32) * ((N + 31) / 32);
-#define WA_CASE(E) case E: hipLaunchKernelGGL((k_gemm_exact<E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); break;
+    static const bool no_dma = getenv("WHISPER_AMD_NO_GEMM_DMA") != nullptr;
+    const bool dma = !no_dma && K % 64 == 0 && K >= 256 && lda % 8 == 0 && ldw % 8 == 0;
+#define WA_CASE(E) case E: if (dma) hipLaunchKernelGGL((k_gemm_exact_dma<E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); \
+                           else     hipLaunchKernelGGL((k_gemm_exact<E>), dim3(grid), dim3(256), 0, s, A, lda, W, ldw, M, N, K, e); break;
     switch (mode) {
         WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_ENC_QKV) WA_CASE(WA_EPI_GELU_F16) WA_CASE(WA_EPI_RESID)
         WA_CASE(WA_EPI_CONV2) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_CROSS_KV) WA_CASE(WA_EPI_DEC_QKV)
