@@ -703,6 +703,207 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same attention for NQ queries of one head per block (RS == 1 only): K and V rows are loaded ONCE per block and used for all NQ
+// queries.  One query per block re-reads the head's whole K and V per query - at T = 1500 that is 6.9 GB of L2 traffic per encoder
+// layer (590 us, half of the reference-order encoder); the arithmetic per query is exactly k_attn_exact's.
+// Dynamic LDS: sc [NQ][kvp] f32 | gs [NQ][kvp / 8] f32 | part [NQ][32 * 64] f32 | p16 [NQ][kvp] f16, kvp = n_kv rounded up to 32.
+// -------------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ __launch_bounds__(ATT_THREADS) void k_attn_exact_mq(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
+                                                               int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
+                                                               int n_tokens, int n_kv, int kvp, const int8_t * __restrict__ mask, float scale,
+                                                               wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out,
+                                                               float * __restrict__ out32, int8_t * __restrict__ q8, float * __restrict__ q8d) {
+    constexpr int NW = ATT_THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mq_smem[];
+    float  * sc   = (float *) mq_smem;                                  // [NQ][kvp]
+    float  * gs   = sc + (size_t) NQ * kvp;                             // [NQ][kvp / 8]
+    float  * part = gs + (size_t) NQ * (kvp >> 3);                      // [NQ][32 * 64]
+    wa_f16 * p16  = (wa_f16 *) (part + (size_t) NQ * 32 * 64);         // [NQ][kvp]
+    __shared__ float red[NQ][NW];
+    __shared__ double redd[NQ][NW];
+    __shared__ float s_inv[NQ];
+    __shared__ __attribute__((aligned(16))) wa_f16 qs[NQ][64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_head = gridDim.x;
+    const int h = blockIdx.x, j0 = blockIdx.y * NQ;
+    const wa_f16 * kp = kbase + (size_t) h * k_head_stride;
+    const wa_f16 * vp = vbase + (size_t) h * v_head_stride;
+
+    if (tid < 64 * NQ) { const int qi = tid >> 6, jq = min(j0 + qi, n_tokens - 1); qs[qi][tid & 63] = q[(size_t) jq * ldq + h * 64 + (tid & 63)]; }
+    __syncthreads();
+
+    // ---- scores: 4 lanes per key; lane a owns partial sums j = a (elements 8a..8a+7 and 32+8a..32+8a+7) ----
+    float lmax[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) lmax[qi] = -INFINITY;
+    {
+        const int a = tid & 3, kslot = tid >> 2;                 // 128 keys per pass
+        float qa[NQ][8], qb[NQ][8];
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) { qa[qi][l] = h2f(qs[qi][8 * a + l]); qb[qi][l] = h2f(qs[qi][32 + 8 * a + l]); }
+        constexpr int KB = 4;                                    // keys per lane group whose K loads are issued together
+        typedef unsigned mq_u4 __attribute__((ext_vector_type(4)));
+        for (int c0 = 0; c0 < n_kv; c0 += (ATT_THREADS / 4) * KB) {
+            mq_u4 ka[KB], kb[KB];
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                int c = c0 + b * (ATT_THREADS / 4) + kslot; c = c < n_kv ? c : n_kv - 1;
+                const wa_f16 * kr = kp + (size_t) c * k_row_stride;
+                ka[b] = *(const mq_u4 *) (kr + 8 * a);
+                kb[b] = *(const mq_u4 *) (kr + 32 + 8 * a);
+            }
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const int c = c0 + b * (ATT_THREADS / 4) + kslot;
+                float k8a[8], k8b[8];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    k8a[2 * l] = h2f((wa_f16) (ka[b][l] & 0xffffu)); k8a[2 * l + 1] = h2f((wa_f16) (ka[b][l] >> 16));
+                    k8b[2 * l] = h2f((wa_f16) (kb[b][l] & 0xffffu)); k8b[2 * l + 1] = h2f((wa_f16) (kb[b][l] >> 16));
+                }
+#pragma unroll
+                for (int qi = 0; qi < NQ; ++qi) {
+                    float v[8];
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) {
+                        float t = fmaf(k8a[l], qa[qi][l], 0.0f);
+                        t = fmaf(k8b[l], qb[qi][l], t);
+                        t = t + dpp_f32<0x4e>(t);                // quad_perm [2,3,0,1]: s[j] + s[j+2]
+                        v[l] = t + dpp_f32<0xb1>(t);             // quad_perm [1,0,3,2]: (s0+s2) + (s1+s3)
+                    }
+                    const float t0 = v[0] + v[4], t1 = v[1] + v[5], t2 = v[2] + v[6], t3 = v[3] + v[7];
+                    float r = ((t0 + t1) + (t2 + t3)) * scale;
+                    if (c < n_kv) {
+                        if (mask && mask[(size_t) min(j0 + qi, n_tokens - 1) * n_kv + c]) r = -INFINITY;
+                        if (a == 0) sc[(size_t) qi * kvp + c] = r;
+                        lmax[qi] = fmaxf(lmax[qi], r);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) { const float m = wave_max(lmax[qi]); if (lane == 0) red[qi][wave] = m; }
+    __syncthreads();
+    float mx[NQ];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        mx[qi] = red[qi][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mx[qi] = fmaxf(mx[qi], red[qi][w]);
+    }
+
+    // ---- exp: polynomial for the multiple-of-8 body, libm expf for the tail ----
+    const int n8 = n_kv & ~7, ng = n8 >> 3;
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+        for (int c = tid; c < n_kv; c += ATT_THREADS) { float * p = &sc[(size_t) qi * kvp + c]; *p = c < n8 ? wa_expf(*p - mx[qi]) : wa_expf_libm(*p - mx[qi]); }
+    __syncthreads();
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+        for (int g = tid; g < ng; g += ATT_THREADS) {
+            const float * v = &sc[(size_t) qi * kvp + g * 8];
+            gs[(size_t) qi * (kvp >> 3) + g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+        }
+    __syncthreads();
+    {   // F64 sums in group order (vec.cpp:278-305): summed in parallel, accepted when the order cannot matter, else redone in order
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+            double ps = 0.0;
+            for (int g = tid; g < ng; g += ATT_THREADS) ps += (double) gs[(size_t) qi * (kvp >> 3) + g];
+            for (int c = n8 + tid; c < n_kv; c += ATT_THREADS) ps += (double) sc[(size_t) qi * kvp + c];
+            ps = wave_sum_d(ps);
+            if (lane == 0) redd[qi][wave] = ps;
+        }
+        __syncthreads();
+        if (tid < NQ) {
+            const int qi = tid;
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += redd[qi][w];
+            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
+            const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
+            if (ilo != ihi) {
+                sum = 0.0;
+                for (int g = 0; g < ng; ++g) sum += (double) gs[(size_t) qi * (kvp >> 3) + g];
+                for (int c = n8; c < n_kv; ++c) sum += (double) sc[(size_t) qi * kvp + c];
+                s_inv[qi] = (float) (1.0 / sum);
+            } else s_inv[qi] = ilo;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+        const float inv = s_inv[qi];
+        for (int c = tid; c < n_kv; c += ATT_THREADS) {
+            const float p = sc[(size_t) qi * kvp + c] * inv;
+            if (qk_out && j0 + qi < n_tokens) qk_out[((size_t) (j0 + qi) * n_head + h) * n_kv + c] = p;
+            p16[(size_t) qi * kvp + c] = f2h(p);
+        }
+    }
+    __syncthreads();
+
+    // ---- P V: chains r = c mod 32 (4 per wave), lane = dh; the V rows are loaded once for all NQ queries ----
+    const int np = n_kv & ~31, nsteps = np >> 5;
+    constexpr int RPW = 32 / NW;          // residues per wave
+    float acc[NQ][RPW];
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) acc[qi][i] = 0.0f;
+    const int r0 = wave * RPW;
+    constexpr int CB = 4;                 // steps whose V loads are issued together
+    for (int s0 = 0; s0 < nsteps; s0 += CB) {
+        wa_f16 vv[CB][RPW];
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int sidx = s0 + b < nsteps ? s0 + b : nsteps - 1;
+                vv[b][i] = vp[(size_t) (sidx * 32 + r0 + i) * v_row_stride + lane];
+            }
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+            if (s0 + b < nsteps) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const float vf = h2f(vv[b][i]);
+#pragma unroll
+                    for (int qi = 0; qi < NQ; ++qi) acc[qi][i] = fmaf(vf, h2f(p16[(size_t) qi * kvp + (s0 + b) * 32 + r0 + i]), acc[qi][i]);
+                }
+            }
+    }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) part[(size_t) qi * 2048 + (r0 + i) * 64 + lane] = acc[qi][i];
+    __syncthreads();
+    if (wave < NQ && j0 + wave < n_tokens) {      // wave qi finishes query qi: the tree over the 32 chains, then the leftover cells in order
+        const int qi = wave, j = j0 + qi;
+        float s32[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s32[r] = part[(size_t) qi * 2048 + r * 64 + lane];
+        double sumf = (double) wa_tree32(s32);
+        const int nl = n_kv - np;
+        float prod[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int cc = c < nl ? c : 0;
+            prod[c] = h2f(vp[(size_t) (np + cc) * v_row_stride + lane]) * h2f(p16[(size_t) qi * kvp + np + cc]);
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
+        if (q8) wa_q8_store((float) sumf, j, 2 * h + (lane >> 5), lane & 31, ldo >> 5, q8, q8d);
+        else if (out32) out32[(size_t) j * ldo + h * 64 + lane] = (float) sumf;
+        else out[(size_t) j * ldo + h * 64 + lane] = f2h((float) sumf);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ partial, const wa_f16 * __restrict__ p_left,
                                                      const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride, int n_kv_arg,
                                                      wa_f16 * __restrict__ out, int ldo, const int * __restrict__ dyn, float * __restrict__ out32,
@@ -736,6 +937,17 @@ void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16
     // few (token, head) pairs and a long key range (decode cross-attention): spread the 32 partial-sum chains over 4 blocks
     // per pair and finish in k_attn_combine; otherwise one block per pair finishes in LDS (encoder, prompt, self-attention)
     const bool split = (long) n_tokens * n_head < 512 && n_kv > 512;
+    if (!split && !dyn && n_tokens >= 4 && n_kv <= 2048 && (long) ((n_tokens + 3) / 4) * n_head >= 256) {
+        // enough (query, head) pairs to fill the chip four queries at a time: share the K / V loads between them
+        constexpr int NQ = 4;
+        const int kvp = (n_kv + 31) & ~31;
+        const size_t lds = (size_t) NQ * kvp * 4 + (size_t) NQ * (kvp >> 3) * 4 + (size_t) NQ * 2048 * 4 + (size_t) NQ * kvp * 2;
+        static bool attr_done = false;
+        if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_attn_exact_mq<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr_done = true; }
+        hipLaunchKernelGGL((k_attn_exact_mq<NQ>), dim3(n_head, (n_tokens + NQ - 1) / NQ), dim3(ATT_THREADS), lds, s, q, ldq, kbase, k_head_stride, k_row_stride,
+                           vbase, v_head_stride, v_row_stride, n_tokens, n_kv, kvp, mask, scale, out, ldo, qk_out, out32, q8, q8d);
+        return;
+    }
     if (!split) {
         hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
                            v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32, q8, q8d);
