@@ -102,8 +102,11 @@ __device__ __forceinline__ float wa_gelu(float x, const wa_f16 * __restrict__ ta
 // (qs [row][el / 4][block][el % 4], qd [row][block]).  All 32 lanes of the half-wave must be active.
 __device__ __forceinline__ void wa_q8_store(float y, int row, int blk, int el, int nb, int8_t * __restrict__ qs, float * __restrict__ qd) {
     float a = fabsf(y);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) a = fmaxf(a, __shfl_xor(a, o, 32));
+    a = fmaxf(a, dpp_f32<0x128>(a));        // row_ror:8, 4, 2, 1: the maximum over a 16-lane row, in every lane of it (one VALU op each;
+    a = fmaxf(a, dpp_f32<0x124>(a));        //  five ds_bpermute exchanges here were half of a single-row LayerNorm launch)
+    a = fmaxf(a, dpp_f32<0x122>(a));
+    a = fmaxf(a, dpp_f32<0x121>(a));
+    a = fmaxf(a, __shfl_xor(a, 16, 32));    // the block's two rows
     const float d = a / 127.f;
     const float id = a != 0.0f ? 127.f / a : 0.0f;
     qs[(((size_t) row * 8 + (el >> 2)) * nb + blk) * 4 + (el & 3)] = (int8_t) (int) rintf(y * id);      // to nearest, ties to even
