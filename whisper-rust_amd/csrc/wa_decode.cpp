@@ -179,7 +179,8 @@ static void decode_launch_quant(whisper_context & ctx, whisper_state & st, int n
         qmul(mode, L, M, e);
     };
     auto ln_q = [&](const float * x, int rows, const wa_ln & ln) {
-        wa_launch_layernorm_exact(s, x, d, rows, d, ln.w, ln.b, hp.eps, nullptr, 0, nullptr, 0, st.d_q8, st.d_q8d);
+        if (rows == 1 && d <= 2048) wa_launch_ln_q8_row(s, x, d, ln.w, ln.b, hp.eps, st.d_q8, st.d_q8d);
+        else wa_launch_layernorm_exact(s, x, d, rows, d, ln.w, ln.b, hp.eps, nullptr, 0, nullptr, 0, st.d_q8, st.d_q8d);
     };
     wa_launch_dec_embed_q(s, st.d_tok, st.d_pos, n_tokens, d, m.te_q.qs, m.te_q.qd, m.d_pe, st.d_dx);
     const float KQscale = pow(float(64), -0.25);

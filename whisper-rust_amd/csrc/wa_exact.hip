@@ -278,7 +278,8 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 // Block-wide LayerNorm of one F32 row (reference-order semantics, certified F64 sums), written as F16 into `dst`.
 // All 256 threads share the row, so each touches K/256 elements: the prologue is issue-bound, not bandwidth-bound.
 __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr, int K, const wa_ln_in & ln, wa_f16 * __restrict__ dst,
-                                                   double * __restrict__ red /*[16] shared*/, float * __restrict__ lrow /*[K] shared*/, int tid) {
+                                                   double * __restrict__ red /*[16] shared*/, float * __restrict__ lrow /*[K] shared*/, int tid,
+                                                   int8_t * __restrict__ qs = nullptr, float * __restrict__ qd = nullptr /* when set: the row as Q8_0 (wa_q8_store, K % 32 == 0) */) {
     const int lane = tid & 63, wave = tid >> 6;
     float xv[GEMV_LN_NPL], gw[GEMV_LN_NPL], gb[GEMV_LN_NPL];
 #pragma unroll
@@ -325,10 +326,23 @@ __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr
             y = y * scale;
             y = y * gw[k];
             y = y + gb[k];
-            dst[i] = f2h(y);
+            if (dst) dst[i] = f2h(y);
+            if (qs) wa_q8_store(y, 0, i >> 5, i & 31, K >> 5, qs, qd);
         }
     }
     __syncthreads();       // `red` is reused by the next row
+}
+
+// one F32 row -> LayerNorm -> Q8_0, by a whole block (the decode step of a quantised model: one wave per row, k_layernorm_exact, leaves
+// a single wave with 20 elements per lane; here every thread has at most 8)
+__global__ __launch_bounds__(GEMV_THREADS) void k_ln_q8_row(const float * __restrict__ x, int K, wa_ln_in ln, int8_t * __restrict__ qs, float * __restrict__ qd) {
+    __shared__ double red[16];
+    __shared__ __attribute__((aligned(16))) float lrow[GEMV_THREADS * GEMV_LN_NPL];
+    wa_block_layernorm(x, K, ln, nullptr, red, lrow, threadIdx.x, qs, qd);
+}
+void wa_launch_ln_q8_row(hipStream_t stream, const float * x, int K, const float * w, const float * b, float eps, int8_t * qs, float * qd) {
+    wa_ln_in ln; ln.x = x; ln.ldx = K; ln.w = w; ln.b = b; ln.eps = eps;
+    hipLaunchKernelGGL(k_ln_q8_row, dim3(1), dim3(GEMV_THREADS), 0, stream, x, K, ln, qs, qd);
 }
 
 template <int MT, int EPI>

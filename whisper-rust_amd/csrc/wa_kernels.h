@@ -107,6 +107,8 @@ void wa_launch_quantize_q8_0(hipStream_t stream, const float * x, int ldx, int r
 // C[M][N] = xq . Wq^T, ggml_vec_dot_q5_0_q8_0 / q8_0_q8_0 order; wq int8 [N][8][K/32][4], wd f32 [N][K/32] (wa_internal.h: wa_lin); any M
 void wa_launch_qgemm_exact(hipStream_t stream, wa_epi_mode mode, const int8_t * xq, const float * xd, int M, const int8_t * wq, const float * wd, int N, int K,
                            const wa_epi & e);
+// one row (K <= 2048, K % 32 == 0): LayerNorm in reference order, quantised to Q8_0 row 0 of (qs, qd), by one 256-thread block
+void wa_launch_ln_q8_row(hipStream_t stream, const float * x, int K, const float * w, const float * b, float eps, int8_t * qs, float * qd);
 // M == 1: GELU(x Wq^T + bias) quantised to Q8_0 straight away (the operand of the second MLP product); N % 32 == 0
 void wa_launch_qgemv_gelu_q8(hipStream_t stream, const int8_t * xq, const float * xd, const int8_t * wq, const float * wd, int N, int K, const float * bias,
                              const wa_f16 * gelu, int8_t * oq, float * oqd);
