@@ -7,7 +7,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "small"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 n_past = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 flash = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
-lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
+lib = W.load_library(os.environ.get("WA_LIB")); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
 mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)      # "small:q5_0" = the quantised file
 ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib, flash_attn=flash), lib=lib)
 st = ctx.create_state()
