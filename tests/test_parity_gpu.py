@@ -232,6 +232,27 @@ def test_flash_path_within_tolerance(env):
     ctx.free()
 
 
+def test_flash_path_small_audio_ctx(wrs, amd_lib):
+    """The tolerance path on reduced audio contexts (streaming windows; a single key tile, tiles with few valid keys): finite and
+    within the path's tolerance of the reference-order path, which the tests above pin to the reference."""
+    amd_lib.whisper_amd_get_embd_enc.restype = C.c_int64
+    amd_lib.whisper_amd_get_embd_enc.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64]
+    pcm = wsynth.synth_audio(16000 * 2, 0)
+    for actx in (50, 257):
+        out = {}
+        for flash in (False, True):
+            ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), wrs.WhisperContextParameters(amd_lib, flash_attn=flash), lib=amd_lib)
+            d = ctx.model_n_audio_state()
+            st = ctx.create_state()
+            st.full(wrs.FullParams(amd_lib, 0, best_of=1, temperature_inc=0.0, audio_ctx=actx, single_segment=True), pcm)
+            buf = np.zeros(1500 * d, np.float32)
+            amd_lib.whisper_amd_get_embd_enc(st.ptr, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size)
+            out[flash] = buf[:actx * d].copy()
+            st.free(); ctx.free()
+        assert np.isfinite(out[True]).all()
+        assert np.abs(out[True] - out[False]).max() <= 1e-2, actx
+
+
 # ------------------------------------------------------------------------------------------------------------
 # mid size, live oracle; full size, properties
 # ------------------------------------------------------------------------------------------------------------
