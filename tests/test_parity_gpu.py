@@ -331,6 +331,24 @@ def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok
     ref.free(); meg.free(); ctx.free()
 
 
+def test_one_launch_step_reduced_audio_ctx(wrs, amd_lib, monkeypatch):
+    """The one-launch step on reduced audio contexts (streaming windows): T below one 32-cell chain step, not a multiple of 8 / 32,
+    a single leftover cell - segments, ids and probabilities identical to the launch sequence."""
+    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    pcm = wsynth.synth_audio(16000 * 3, 5)
+    for actx in (1, 7, 33, 50, 257):
+        res = {}
+        for nomega in ("1", "0"):
+            monkeypatch.setenv("WHISPER_AMD_NO_MEGA", nomega)
+            st = ctx.create_state()
+            st.full(wrs.FullParams(amd_lib, 0, best_of=1, temperature_inc=0.0, audio_ctx=actx, single_segment=True), pcm)
+            res[nomega] = [(s["t0"], s["t1"], s["ids"], s["p"], s["plog"]) for s in st.segments()]
+            st.free()
+        assert sum(len(s[2]) for s in res["0"]) > 0
+        assert res["0"] == res["1"], actx
+    ctx.free()
+
+
 def test_host_overlap_never_changes_results(wrs, amd_lib, monkeypatch):
     """Greedy decoding with the device predicting the next token (host overlap) must give the segments of the plain loop -
     also when the prediction is wrong on purpose (every third token id hidden from the device), which exercises the
