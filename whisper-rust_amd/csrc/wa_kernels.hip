@@ -302,8 +302,7 @@ static void gemm_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int
 
 void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
                     const wa_epi & e) {
-    // 128x128 tiles when that still yields >= 256 blocks (one per CU); 64x64 otherwise.
-    const long big = (long) ((M + 127) / 128) * ((N + 127) / 128);
+    const long big = (long) ((M + 127) / 128) * ((N + 127) / 128);      // number of 128x128 tiles
     static const bool no_dma = getenv("WHISPER_AMD_NO_GEMM_DMA") != nullptr;
     if (!no_dma && K % G2_BK == 0 && K / G2_BK >= 4 && lda % 8 == 0 && ldw % 8 == 0) {
         // 64-tiles (4 stages = 64 KB, two workgroups per CU) everywhere.  128-tiles (3 stages = 96 KB, one workgroup per CU) halve the
@@ -318,9 +317,7 @@ void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int 
         else                                 gemm_dma_dispatch<64, 4, 4>(stream, mode, A, lda, W, ldw, M, N, K, e);
         return;
     }
-    static const long thr = getenv("WHISPER_AMD_GEMM_THR") ? atol(getenv("WHISPER_AMD_GEMM_THR")) : 1000000;   // measured on ggml-small shapes (M = 1500): 64x64 tiles (>= 4 blocks per CU) beat 128x128 on every GEMM of the encoder
-    if (big >= thr) gemm_dispatch<128, 128>(stream, mode, A, lda, W, ldw, M, N, K, e);
-    else            gemm_dispatch<64, 64>(stream, mode, A, lda, W, ldw, M, N, K, e);
+    gemm_dispatch<64, 64>(stream, mode, A, lda, W, ldw, M, N, K, e);        // K % 64 != 0 or K < 256: the register-staged form
 }
 
 // =================================================================================================
