@@ -468,6 +468,9 @@ WHISPER_API int whisper_amd_decode_step_probe(struct whisper_context * ctx, stru
 /* 1 when the state runs the single-token decoder pass as ONE persistent launch (wa_mega.hip), 0 when it replays the
  * captured launch sequence (WHISPER_AMD_NO_MEGA=1, unsupported shape, or after a hand-off time-out). */
 WHISPER_API int whisper_amd_mega_enabled(struct whisper_state * state);
+/* Role of workgroup `wg` of the n_wg workgroups of the one-launch step for a model with n_head text heads (no device needed): role 0 =
+ * weight streaming (index = its rank), 1 = self-attention of head `index`, 2 = cross-attention (index = 4 head + quarter). */
+WHISPER_API void whisper_amd_mega_role_of(int n_wg, int n_head, int wg, int * role, int * index);
 
 /* Host-overlapped greedy decoding (the device decodes its own prediction of the next token while the host applies the
  * reference's sampling rules to the previous logits): out = { predictions confirmed, predictions wrong (step redone) }

@@ -138,3 +138,26 @@ def test_gelu_table_matches_reference_table(amd_lib):
     finite = ~np.isnan(a.view(np.float16)) & ~np.isnan(b.view(np.float16))
     assert np.array_equal(a[finite], b[finite])
     assert np.array_equal(np.isnan(a.view(np.float16)), np.isnan(b.view(np.float16)))
+
+
+def test_one_launch_step_role_map(amd_lib):
+    """Workgroup -> role map of the one-launch decode step (wa_mega.h: mg_role_of), a pure function: every role index exactly once
+    for every head count, and the four cross-attention workgroups of a head 8 workgroups apart (one XCD under round-robin dispatch)."""
+    f = amd_lib.whisper_amd_mega_role_of
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    f.restype = None
+    for n_wg in (256, 250):                    # 250: not a multiple of 8 -> the plain layout
+        for H in (1, 2, 3, 6, 8, 12, 16, 20, 32):
+            seen = {}
+            for b in range(n_wg):
+                role, idx = C.c_int(-1), C.c_int(-1)
+                f(n_wg, H, b, C.byref(role), C.byref(idx))
+                assert (role.value, idx.value) not in seen
+                seen[(role.value, idx.value)] = b
+            n_g = n_wg - 5 * H
+            assert sorted(i for r, i in seen if r == 0) == list(range(n_g))
+            assert sorted(i for r, i in seen if r == 1) == list(range(H))
+            assert sorted(i for r, i in seen if r == 2) == list(range(4 * H))
+            if n_wg % 8 == 0:
+                for h in range(H):
+                    assert len({seen[(2, 4 * h + w)] % 8 for w in range(4)}) == 1, (H, h)

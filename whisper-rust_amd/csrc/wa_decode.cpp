@@ -537,6 +537,9 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     return 0;
 }
 
+// the workgroup -> role map of the one-launch step (wa_mega.h), for the CPU tests
+extern "C" void whisper_amd_mega_role_of(int n_wg, int n_head, int wg, int * role, int * index) { mg_role_of(n_wg, n_head, wg, *role, *index); }
+
 // -------------------------------------------------------------------------------------------------
 // debugging aid (tools/mega_check.py): run the one-launch step for (token, pos) on KV cell `n_past` and copy out the
 // hand-off granules [layer][8][2d] (tag << 32 | value) and the logits.  KV metadata is not touched.

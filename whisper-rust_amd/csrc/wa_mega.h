@@ -51,6 +51,36 @@ struct wa_mega_args {
 #define WA_MEGA_MAX_KV 512
 #define WA_MEGA_MAX_T 1536
 
+#if defined(__HIPCC__)
+#define WA_HD __host__ __device__
+#else
+#define WA_HD
+#endif
+// Role of workgroup b of n (role 0: weight streaming, index = its rank; 1: self-attention of head index; 2: cross-attention, index =
+// 4 head + quarter).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one - observed, not promised: the
+// cross-attention role checks it at run time), so with n % 8 == 0 the four quarters of a head are placed 8 apart: their three
+// exchanges per layer then stay inside one L2.  Heads sit in groups of 8 at the top of the grid; the slots of a group that
+// has fewer than 8 heads go to self-attention first, then to weight streaming.
+WA_HD inline void mg_role_of(int n, int H, int b, int & role, int & idx) {
+    const int G8 = (H + 7) >> 3, top = n - 32 * G8;
+    const int R = H - 8 * (G8 - 1);                     // heads in the last group (1..8)
+    const int F = 4 * (8 - R);                          // free slots up there
+    const int s_low = H > F ? H - F : 0;                // self-attention heads placed below `top`
+    if ((n & 7) != 0 || top - s_low < 1) {              // plain layout
+        const int nG = n - 5 * H;
+        if (b < nG) { role = 0; idx = b; } else if (b < nG + H) { role = 1; idx = b - nG; } else { role = 2; idx = b - nG - H; }
+        return;
+    }
+    if (b >= top) {
+        const int t = b - top, r = t & 7, k = t >> 3, q = k >> 2, w = k & 3, h = r + 8 * q;
+        if (h < H) { role = 2; idx = 4 * h + w; return; }
+        const int f = (r - R) + (8 - R) * w;            // free slot number
+        if (f < H) { role = 1; idx = f; } else { role = 0; idx = (top - s_low) + (f - H); }
+        return;
+    }
+    if (b >= top - s_low) { role = 1; idx = F + (b - (top - s_low)); } else { role = 0; idx = b; }
+}
+
 // n_wg workgroups of 512 threads, every one of them resident at once (n_wg <= number of CUs; 1 workgroup per CU)
 void   wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg);
 size_t wa_mega_lds_bytes();

@@ -56,30 +56,6 @@ __device__ __forceinline__ void gr_store_l(gu64 * g, unsigned seq, unsigned v, b
     else       __hip_atomic_store(g, ((u64) seq << 32) | (u64) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Role of workgroup b of n (role 0: weight streaming, index = its rank; 1: self-attention of head index; 2: cross-attention, index =
-// 4 head + quarter).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one - observed, not promised: the
-// cross-attention role checks it at run time), so with n % 8 == 0 the four quarters of a head are placed 8 apart: their three
-// exchanges per layer then stay inside one L2.  Heads sit in groups of 8 at the top of the grid; the slots of a group that
-// has fewer than 8 heads go to self-attention first, then to weight streaming.
-__device__ __forceinline__ void mg_role_of(int n, int H, int b, int & role, int & idx) {
-    const int G8 = (H + 7) >> 3, top = n - 32 * G8;
-    const int R = H - 8 * (G8 - 1);                     // heads in the last group (1..8)
-    const int F = 4 * (8 - R);                          // free slots up there
-    const int s_low = H > F ? H - F : 0;                // self-attention heads placed below `top`
-    if ((n & 7) != 0 || top - s_low < 1) {              // plain layout
-        const int nG = n - 5 * H;
-        if (b < nG) { role = 0; idx = b; } else if (b < nG + H) { role = 1; idx = b - nG; } else { role = 2; idx = b - nG - H; }
-        return;
-    }
-    if (b >= top) {
-        const int t = b - top, r = t & 7, k = t >> 3, q = k >> 2, w = k & 3, h = r + 8 * q;
-        if (h < H) { role = 2; idx = 4 * h + w; return; }
-        const int f = (r - R) + (8 - R) * w;            // free slot number
-        if (f < H) { role = 1; idx = f; } else { role = 0; idx = (top - s_low) + (f - H); }
-        return;
-    }
-    if (b >= top - s_low) { role = 1; idx = F + (b - (top - s_low)); } else { role = 0; idx = b; }
-}
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xf, 0xf, true); }
 
