@@ -502,7 +502,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
 // Every wave loads the weights of its NEXT task right after finishing the current one.
 // -------------------------------------------------------------------------------------------------
 template <int NP3, int NS>
-__device__ __noinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
+__device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int lane = threadIdx.x & 63;
@@ -798,7 +798,7 @@ __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 
 // role: self-attention of head h (whisper.cpp:2636-2651), every layer.  The K/V cells of earlier tokens are copied
 // into LDS while the GEMV workgroups are busy with the previous phases; the new cell arrives with the query.
 // -------------------------------------------------------------------------------------------------
-__device__ __noinline__ void mg_role_self(mg_kargs A_, int idx_) {
+__device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -933,7 +933,7 @@ __device__ __noinline__ void mg_role_self(mg_kargs A_, int idx_) {
 #define MG_CGR_XCC 16                                   // (layer 0 area only) the four workgroups' XCC_IDs
 #define MG_CGR_PART 64                                  // + (w - 1) * 576: 512 chain sums + 8 leftover probabilities
 
-__device__ __noinline__ void mg_role_cross(mg_kargs A_, int idx_) {
+__device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     const int tid = threadIdx.x, lane = tid & 63;
