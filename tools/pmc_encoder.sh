@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_enc_${2:-a}; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/encode_probe.py small 1 2 > $OUT/log.txt 2>&1
+rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/encode_probe.py small ${3:-1} 2 > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(list)

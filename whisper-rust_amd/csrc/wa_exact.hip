@@ -175,8 +175,159 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact_dma(const wa_f16 * __rest
         }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same product ON THE MATRIX CORES, still bit-identical.  v_mfma_f32_16x16x4_f32 computes, per output element,
+// fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, c)))) - an ascending F32 fmaf chain (tools/micro/mfma_f32_exact.hip: 0 mismatches
+// in 10^5 random outputs, F16-valued and arbitrary operands, chained 24 deep).  One of the reference's 32 partial sums of an output,
+// s[r] (elements k = 32 s + r, s ascending: vec.cpp:191-231), is exactly such a chain, so partial sum r of a 16 x 16 output tile is
+// one accumulator tile fed with the k-elements r, 32 + r, 64 + r, 96 + r of every 128-k stage: 32 accumulator tiles (128 VGPRs) per
+// wave, the final tree (wa_tree32) lane-local as before.  Rate = the F32 MFMA's (155 TFLOP/s, the same peak as the VALU form - but
+// the VALU form spent its issue slots on conversions and operand traffic and reached 20 % of it).
+//   * workgroup = 4 waves as 2 x 2, tile 32 x 32, wave tile 16 x 16; MX_WGS workgroups per CU (<= 168 VGPRs), each with its own
+//     barrier: while one waits for a stage or issues its loads, the others' MFMAs keep the SIMD's matrix pipe busy (one 8-wave
+//     workgroup per CU, every wave at the same barrier every stage, reached 43 % of the MFMA rate);
+//   * operands by LDS-DMA into a ring of NST stages of 128 k (A 8 KB + W 8 KB), 4 pieces per wave and stage, one LDS-only
+//     barrier per stage;
+//   * a lane's fragment read is ONE 16-byte piece = its (row, k-step) element of 8 consecutive partial sums; the slot of chunk c
+//     of row r is c ^ g(r) with g = (r & 15) ^ (4 if 4 <= r & 15 <= 11): conflict-free over ds_read_b128's lane groups
+//     ({0-3, 12-15, 20-27}, ... - MI355X guide, LDS), which mix two k-steps.
+// K % 128 == 0 (a partial sum's chain then is whole MFMAs); other shapes take the VALU kernels above.
+// -------------------------------------------------------------------------------------------------
+#define MX_NST 3                                             // 48 KB of LDS per workgroup
+#define MX_BM 32
+#define MX_BN 32
+#define MX_STAGE_HALFS ((MX_BM + MX_BN) * 128)
+#define MX_PCS 4                                             // 1 KB pieces per wave and stage
+__device__ __forceinline__ int mx_g(int row) { const int r = row & 15; return r ^ ((r >= 4 && r <= 11) ? 4 : 0); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_exact_mfma(const wa_f16 * __restrict__ A, int lda, const wa_f16 * __restrict__ W, int ldw,
+                                                            int M, int N, int K, wa_epi e) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char mx_smem[];
+    wa_f16 * S = (wa_f16 *) mx_smem;                         // [MX_NST][A 32 x 128 | W 32 x 128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order (as k_gemm_f16_dma): XCD x takes a contiguous eighth of the tiles, cut along the longer of M and N
+    const int tiles_m = (M + MX_BM - 1) / MX_BM, tiles_n = (N + MX_BN - 1) / MX_BN, per_xcd = (tiles_m * tiles_n + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= tiles_m * tiles_n) return;
+    const int bm = N > M ? t % tiles_m : t / tiles_n, bn = N > M ? t / tiles_m : t % tiles_n;
+    const int m0 = bm * MX_BM, n0 = bn * MX_BN;
+
+    // this wave's four 1 KB pieces of a stage: A rows [8 wave, 8 wave + 8) and W rows [8 wave, 8 wave + 8); a piece = 4 rows x 16 slots
+    const int prow = lane >> 4, pslot = lane & 15;
+    unsigned goff[MX_PCS];                                   // byte offset of this lane's 16 bytes from A / W (uniform base + 32-bit lane offset)
+    int ldst[MX_PCS];
+#pragma unroll
+    for (int p = 0; p < MX_PCS; ++p) {
+        const int row = 8 * wave + 4 * (p & 1) + prow;
+        const int chunk = pslot ^ mx_g(row);
+        goff[p] = p < 2 ? ((unsigned) min(m0 + row, M - 1) * (unsigned) lda + chunk * 8) * 2u : ((unsigned) min(n0 + row, N - 1) * (unsigned) ldw + chunk * 8) * 2u;
+        ldst[p] = (p < 2 ? 0 : MX_BM * 128) + (row - prow) * 128;      // piece base (the DMA adds lane * 16 B itself)
+    }
+    const int nk = K >> 7;
+    const __attribute__((address_space(1))) char * Ab = (const __attribute__((address_space(1))) char *) A, * Wb = (const __attribute__((address_space(1))) char *) W;
+#define MX_ISSUE(kt_) do { const int k0_ = min((kt_), nk - 1) * 256; wa_f16 * st_ = S + ((kt_) % MX_NST) * MX_STAGE_HALFS; \
+        _Pragma("unroll") for (int p = 0; p < MX_PCS; ++p) \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) ((p < 2 ? Ab : Wb) + k0_ + goff[p]), (__attribute__((address_space(3))) void *) (st_ + ldst[p]), 16, 0, 0); \
+        } while (0)
+
+    f32x4 acc[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < MX_NST - 1; ++p) MX_ISSUE(p);
+
+    // epilogue operands now (clamped, unconditional): D row = 4 (lane / 16) + j, column = lane % 16
+    const int fr = lane & 15, fk = lane >> 4;
+    const int on = n0 + wn * 16 + fr, om = m0 + wm * 16 + 4 * fk;
+    constexpr bool RES = EPI == WA_EPI_RESID || EPI == WA_EPI_CONV2;
+    const wa_epi_pre pcol = epi_preload<RES ? WA_EPI_F32 : EPI>(e, 0, min(on, N - 1));
+    float pres[4] = { 0.f, 0.f, 0.f, 0.f };
+    if (RES) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pres[j] = e.resid[(size_t) min(om + j, M - 1) * e.ldr + min(on, N - 1)];
+    }
+    // fragment addresses: row (wm 16 + fr | wn 16 + fr), k-step fk of the stage, chunk 4 fk + c -> slot (4 fk + c) ^ g(row)
+    const int ga = mx_g(fr);
+    const wa_f16 * fa = S + (wm * 16 + fr) * 128, * fw = S + MX_BM * 128 + (wn * 16 + fr) * 128;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed when at most the (MX_NST - 2) x MX_PCS loads this wave issued after it are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((MX_NST - 2) * MX_PCS) : "memory");
+        const int so = (kt % MX_NST) * MX_STAGE_HALFS;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                     // four fragment reads in flight before the first conversion of a half
+            half8 af[2], wf[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                af[c] = *(const half8 *) (fa + so + (((4 * fk + 2 * hf + c) ^ ga) * 8));
+                wf[c] = *(const half8 *) (fw + so + (((4 * fk + 2 * hf + c) ^ ga) * 8));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (hf == 0) {
+                MX_ISSUE(kt + MX_NST - 1);    // into the stage read in the previous iteration: every wave is past it (barrier)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    acc[(2 * hf + c) * 8 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32((float) af[c][i], (float) wf[c][i], acc[(2 * hf + c) * 8 + i], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus loads of the last iterations still target this block's LDS
+#undef MX_ISSUE
+    float res[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s32[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s32[r] = acc[r][j];
+        res[j] = wa_tree32(s32);
+    }
+    if (EPI == WA_EPI_GELU_F16 || EPI == WA_EPI_CONV2) {       // the four table look-ups in flight together
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float v = res[j]; if (e.bias) v = v + pcol.bias; res[j] = wa_gelu_nb(v, e.gelu); }
+    }
+    if (on >= N) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = om + j;
+        if (m >= M) continue;
+        if (EPI == WA_EPI_GELU_F16) ((wa_f16 *) e.out)[(size_t) m * e.ldo + on] = f2h(res[j]);
+        else if (EPI == WA_EPI_CONV2) {
+            if (e.dbg) e.dbg[(size_t) m * e.ldo + on] = res[j];
+            ((float *) e.out)[(size_t) m * e.ldo + on] = pres[j] + res[j];
+        } else {
+            wa_epi_pre pre = pcol;
+            if (RES) pre.resid = pres[j];
+            epi_apply<EPI>(e, m, on, res[j], pre);
+        }
+    }
+}
+
+template <int EPI>
+static void gemm_exact_mfma_launch(hipStream_t s, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
+    static bool attr_done = false;
+    constexpr int lds = MX_NST * MX_STAGE_HALFS * 2;
+    if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_gemm_exact_mfma<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
+    const int grid = ((((M + MX_BM - 1) / MX_BM) * ((N + MX_BN - 1) / MX_BN) + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_gemm_exact_mfma<EPI>), dim3(grid), dim3(256), lds, s, A, lda, W, ldw, M, N, K, e);
+}
+
 void wa_launch_gemm_exact(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
                           const wa_epi & e) {
+    static const bool no_mfma = getenv("WHISPER_AMD_NO_EXACT_MFMA") != nullptr;
+    if (!no_mfma && K % 128 == 0 && lda % 8 == 0 && ldw % 8 == 0) {
+#define WA_CASE(E) case E: gemm_exact_mfma_launch<E>(s, A, lda, W, ldw, M, N, K, e); return;
+        switch (mode) {
+            WA_CASE(WA_EPI_F16) WA_CASE(WA_EPI_ENC_QKV) WA_CASE(WA_EPI_GELU_F16) WA_CASE(WA_EPI_RESID)
+            WA_CASE(WA_EPI_CONV2) WA_CASE(WA_EPI_F32) WA_CASE(WA_EPI_CROSS_KV) WA_CASE(WA_EPI_DEC_QKV)
+            default: break;
+        }
+#undef WA_CASE
+    }
     const int grid = ((M + 31) / 32) * ((N + 31) / 32);
     static const bool no_dma = getenv("WHISPER_AMD_NO_GEMM_DMA") != nullptr;
     const bool dma = !no_dma && K % 64 == 0 && K >= 256 && lda % 8 == 0 && ldw % 8 == 0;
