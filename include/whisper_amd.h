@@ -59,6 +59,9 @@ WHISPER_API int  ggml_cpu_has_avx (void);
 WHISPER_API int  ggml_cpu_has_avx2(void);
 WHISPER_API int  ggml_cpu_has_fma (void);
 WHISPER_API int  ggml_cpu_has_f16c(void);
+/* ref: ggml/include/ggml-backend.h (ggml_backend_load_all): the reference's own examples call it before whisper_init_* (examples/bench/
+ * bench.cpp:159, examples/cli); here there is one built-in backend and nothing to load - a no-op kept so that they link unmodified. */
+WHISPER_API void ggml_backend_load_all(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Opaque handles and scalar typedefs            ref: include/whisper.h:80-86
@@ -100,7 +103,8 @@ typedef struct whisper_aheads { size_t n_heads; const whisper_ahead * heads; } w
  * is no CPU path in the product (init returns NULL with an error log). `gpu_device` = HIP device. */
 struct whisper_context_params {
     bool  use_gpu;
-    bool  flash_attn;            /* accepted; only side effect kept: disables DTW (whisper.cpp:3724-3727) */
+    bool  flash_attn;            /* false (default): reference summation order, bit-identical to whisper.cpp CPU; true: F16-MFMA encoder / prompt
+                                    products (tolerance-level parity) and, as in the reference, DTW off (whisper.cpp:3724-3727) */
     int   gpu_device;
     bool  dtw_token_timestamps;
     enum whisper_alignment_heads_preset dtw_aheads_preset;
@@ -182,7 +186,7 @@ struct whisper_full_params {
     bool print_realtime;
     bool print_timestamps;
 
-    bool  token_timestamps;      /* heuristic token timestamps: not implemented */
+    bool  token_timestamps;      /* heuristic per-token t0 / t1 / vlen (whisper.cpp:8326-8616), with max_len / split_on_word wrapping */
     float thold_pt;
     float thold_ptsum;
     int   max_len;

@@ -161,3 +161,24 @@ def test_one_launch_step_role_map(amd_lib):
             if n_wg % 8 == 0:
                 for h in range(H):
                     assert len({seen[(2, 4 * h + w)] % 8 for w in range(4)}) == 1, (H, h)
+
+
+def test_by_value_struct_layout_field_by_field(tmp_path):
+    """Every field of the structs that cross the ABI by value (whisper_context_params 48 B, whisper_full_params 296 B, whisper_token_data
+    56 B, ...): sizeof / alignof / offsetof as a C++ compiler sees them through include/whisper_amd.h == the listing the reference's
+    whisper.h gave (tests/golden/abi_layout.txt); where /root/reference is present the reference header is compiled again and
+    compared too (tests/native/abi_layout.cpp)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "abi_layout.cpp")
+    want = open(os.path.join(ROOT, "tests", "golden", "abi_layout.txt")).read()
+    exe = str(tmp_path / "abi_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-DABI_HEADER=\"whisper_amd.h\"", "-I" + os.path.join(ROOT, "include"), src, "-o", exe])
+    assert subprocess.check_output([exe]).decode() == want
+    exe2 = str(tmp_path / "abi_whisper_h")       # through the drop-in name include/whisper.h as well
+    subprocess.check_call(["g++", "-std=c++17", "-DABI_HEADER=\"whisper.h\"", "-I" + os.path.join(ROOT, "include"), src, "-o", exe2])
+    assert subprocess.check_output([exe2]).decode() == want
+    ref_inc = "/root/reference/sys/whisper.cpp"
+    if os.path.exists(os.path.join(ref_inc, "include", "whisper.h")):
+        exe3 = str(tmp_path / "abi_ref")
+        subprocess.check_call(["g++", "-std=c++17", "-DABI_HEADER=\"whisper.h\"", "-I" + ref_inc + "/include", "-I" + ref_inc + "/ggml/include", src, "-o", exe3])
+        assert subprocess.check_output([exe3]).decode() == want, "the fixture no longer matches the reference header"

@@ -306,7 +306,7 @@ def test_small_shape_properties(wrs, amd_lib):
     st.free(); ctx.free()
 
 
-@pytest.mark.parametrize("name,n_tok", [("s128", 40), ("tiny", 24), ("base", 24), ("small", 48), ("w1280", 12)])
+@pytest.mark.parametrize("name,n_tok", [("s128", 40), ("tiny", 24), ("base", 24), ("small", 48), ("m1024", 12), ("w1280", 12)])
 def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok, monkeypatch):
     """The single-token decoder pass as ONE persistent launch (wa_mega.hip) against the launch sequence (which the tests
     above pin to the reference): bit-identical logits token by token, over enough tokens that n_kv crosses the n % 8 and
@@ -353,6 +353,8 @@ def test_host_overlap_never_changes_results(wrs, amd_lib, monkeypatch):
     """Greedy decoding with the device predicting the next token (host overlap) must give the segments of the plain loop -
     also when the prediction is wrong on purpose (every third token id hidden from the device), which exercises the
     discard-and-redo path; and the predictions must actually have been used / refused."""
+    if os.environ.get("WHISPER_AMD_NO_MEGA", "0") not in ("", "0"):
+        pytest.skip("the host overlap rides on the one-launch step, which WHISPER_AMD_NO_MEGA turns off")
     amd_lib.whisper_amd_overlap_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     amd_lib.whisper_amd_reset_timings.argtypes = [C.c_void_p]
     ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), wrs.WhisperContextParameters(amd_lib), lib=amd_lib)

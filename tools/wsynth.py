@@ -23,6 +23,7 @@ SHAPES = {
     "s128":   dict(d=128,  heads=2,  enc=3,  dec=4,  n_mels=80,  n_vocab=51865),
     "s192":   dict(d=192,  heads=3,  enc=2,  dec=2 + 1, n_mels=80, n_vocab=51865),   # d not a multiple of 128: tile guards
     "w1280":  dict(d=1280, heads=20, enc=1,  dec=3,  n_mels=128, n_vocab=51866),      # large-v3's width with few layers: the wide-model paths
+    "m1024":  dict(d=1024, heads=16, enc=1,  dec=3,  n_mels=80,  n_vocab=51865),      # medium's width and head count with few layers (config 4's products)
     # real Whisper shapes (SURVEY.md §8 header)
     "tiny":   dict(d=384,  heads=6,  enc=4,  dec=4,  n_mels=80,  n_vocab=51865),
     "base":   dict(d=512,  heads=8,  enc=6,  dec=6,  n_mels=80,  n_vocab=51865),

@@ -54,6 +54,7 @@ int ggml_cpu_has_avx (void) { return __builtin_cpu_supports("avx")  ? 1 : 0; }
 int ggml_cpu_has_avx2(void) { return __builtin_cpu_supports("avx2") ? 1 : 0; }
 int ggml_cpu_has_fma (void) { return __builtin_cpu_supports("fma")  ? 1 : 0; }
 int ggml_cpu_has_f16c(void) { return __builtin_cpu_supports("f16c") ? 1 : 0; }
+void ggml_backend_load_all(void) {}
 
 void whisper_amd_abi_sizes(size_t out[6]) {
     out[0] = sizeof(whisper_context_params); out[1] = sizeof(whisper_full_params); out[2] = sizeof(whisper_token_data);
@@ -85,36 +86,30 @@ static const char * const k_lang[100][2] = {
 #define WA_N_LANG 100
 
 // -------------------------------------------------------------------------------------------------
-// tokenizer: regex pre-split + greedy longest match (ref: whisper.cpp:3288-3336)
+// tokenizer (whisper_tokenize, params.initial_prompt).  Contract: whisper.cpp:3288-3336 - GPT-2's pre-tokenisation pattern, then
+// every piece is covered left to right by the LONGEST vocabulary entry that starts at the current byte; a byte no entry starts at is
+// skipped with an error log.  Pinned by the reference engine's goldens (tests/golden/r2_cases.json: "tokenize", initial_prompt).
 // -------------------------------------------------------------------------------------------------
 std::vector<int> wa_tokenize(const wa_vocab & vocab, const std::string & text) {
-    std::vector<std::string> words;
-    {
-        std::string str = text;
-        static const std::regex re(R"('s|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+)");
-        std::smatch m;
-        while (std::regex_search(str, m, re)) {
-            for (auto x : m) words.push_back(x);
-            str = m.suffix();
-        }
-    }
-    std::vector<int> tokens;
-    for (const auto & word : words) {
-        if (word.empty()) continue;
-        int i = 0;
-        const int n = (int) word.size();
-        while (i < n) {
-            int j = n;
-            bool found = false;
-            while (j > i) {
-                auto it = vocab.token_to_id.find(word.substr(i, j - i));
-                if (it != vocab.token_to_id.end()) { tokens.push_back(it->second); i = j; found = true; break; }
-                --j;
+    static const std::regex piece_re(R"('s|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+)");
+    size_t longest = 1;                                    // no entry is longer: bounds the candidate lengths tried per position
+    for (const auto & kv : vocab.token_to_id) longest = std::max(longest, kv.first.size());
+    std::vector<int> ids;
+    std::string cand;
+    for (std::sregex_iterator it(text.begin(), text.end(), piece_re), end; it != end; ++it) {
+        const std::string piece = it->str();
+        for (size_t at = 0; at < piece.size();) {
+            size_t took = 0;
+            for (size_t len = std::min(longest, piece.size() - at); len > 0 && took == 0; --len) {
+                cand.assign(piece, at, len);
+                const auto hit = vocab.token_to_id.find(cand);
+                if (hit != vocab.token_to_id.end()) { ids.push_back(hit->second); took = len; }
             }
-            if (!found) { WA_ERROR("unknown token\n"); ++i; }
+            if (took == 0) { WA_ERROR("unknown token\n"); took = 1; }
+            at += took;
         }
     }
-    return tokens;
+    return ids;
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -233,7 +233,12 @@ static void decode_launch_quant(whisper_context & ctx, whisper_state & st, int n
 // workgroups wait for each other, so two of them interleaved by the dispatcher could each hold CUs the other needs.
 // Returns 1 = done (logits in h_logits_pinned), 0 = not applicable / gave up (caller runs the launch sequence).
 // -------------------------------------------------------------------------------------------------
-static std::mutex g_mega_mutex;
+// One slot per DEVICE (two devices never wait for each other).  Ownership rules: mega_step and the probes hold it for one launch +
+// synchronise; the host-overlap window (wa_spec_begin .. wa_spec_end) holds it while its launches are in flight and records that in
+// st.spec_owner, so that wa_spec_end releases exactly what wa_spec_begin took - also on every failure path (a begin that fails after
+// taking the slot gives it back itself).  While a window owns the slot, other states' single-token steps on that device wait; steps
+// that do not need the slot (several tokens, masks, beams: the launch sequence) run concurrently on their own streams.
+static std::mutex & mega_slot(int device) { static std::mutex m[64]; return m[(unsigned) device & 63u]; }
 
 static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & a, int token, int pos, int n_kv, int kv_head) {
     const auto & m = ctx.model;
@@ -266,7 +271,7 @@ static int mega_step(whisper_context & ctx, whisper_state & st, int token, int p
     hipStream_t s = st.stream;
     unsigned status = 0;
     {
-        std::lock_guard<std::mutex> lk(g_mega_mutex);
+        std::lock_guard<std::mutex> lk(mega_slot(ctx.device));
         wa_launch_decode_mega(s, a, std::min(ctx.model.n_cu, 256));
         (void) hipMemcpyAsync(st.h_logits_pinned, st.d_mega_out, ((size_t) n_vocab + 1) * sizeof(float), hipMemcpyDeviceToHost, s);
         if (!WA_HIP_OK(hipStreamSynchronize(s))) { st.mega_enabled = false; return 0; }
@@ -304,7 +309,6 @@ bool wa_spec_begin(whisper_context & ctx, whisper_state & st, const std::vector<
         }
         if (!WA_HIP_OK(hipStreamCreateWithFlags(&st.copy_stream, hipStreamNonBlocking))) { st.copy_stream = nullptr; return false; }
     }
-    g_mega_mutex.lock();       // exclusive use of the device's one-launch slot until wa_spec_end
     std::vector<uint32_t> sab;
     if (const char * e = getenv("WHISPER_AMD_OVERLAP_SABOTAGE")) {      // tests: make the device's prediction wrong on purpose (every
         if (e[0] == '1') {                                              // 3rd token id is hidden from it) - results must not change
@@ -314,15 +318,18 @@ bool wa_spec_begin(whisper_context & ctx, whisper_state & st, const std::vector<
     }
     const std::vector<uint32_t> & up = sab.empty() ? bits : sab;
     (void) hipMemcpyAsync(st.d_mega_smask, up.data(), up.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st.stream);
-    return WA_HIP_OK(hipStreamSynchronize(st.stream));
+    if (!WA_HIP_OK(hipStreamSynchronize(st.stream))) return false;
+    mega_slot(ctx.device).lock();       // last: nothing below can fail, so a false return never leaves the slot taken
+    st.spec_owner = true;
+    return true;
 }
 
-void wa_spec_end(whisper_context &, whisper_state & st) {
+void wa_spec_end(whisper_context & ctx, whisper_state & st) {
     (void) hipStreamSynchronize(st.stream);
-    (void) hipStreamSynchronize(st.copy_stream);
+    if (st.copy_stream) (void) hipStreamSynchronize(st.copy_stream);
     (void) hipMemsetAsync(st.d_mega_smask, 0, ((size_t) st.ctx->model.hp.n_vocab / 32 + 2) * sizeof(uint32_t), st.stream);   // plain steps use no mask
     (void) hipStreamSynchronize(st.stream);
-    g_mega_mutex.unlock();
+    if (st.spec_owner) { st.spec_owner = false; mega_slot(ctx.device).unlock(); }      // idempotent: only the owner gives the slot back
 }
 
 bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, int token, const wa_spec_state & after) {
@@ -490,7 +497,7 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
     if (st->mega_enabled) {     // the one-launch step: n_iters launches back to back, each with its own sequence number
         wa_mega_args a;
         if (mega_args(*ctx, *st, a, h[0], n_past, n_past + 1, n_past)) {
-            std::lock_guard<std::mutex> lk(g_mega_mutex);
+            std::lock_guard<std::mutex> lk(mega_slot(ctx->device));
             const int n_wg = std::min(ctx->model.n_cu, 256);
             wa_launch_decode_mega(s, a, n_wg);      // warm-up
             (void) hipEventRecord(e0, s);
@@ -554,7 +561,7 @@ extern "C" int whisper_amd_mega_debug(struct whisper_context * ctx, struct whisp
     const auto & hp = ctx->model.hp;
     const size_t n_dbg = (size_t) hp.n_text_layer * hp.n_text_head * 5120 + 8192;
     if (getenv("WHISPER_AMD_MEGA_DBG")) { if (!d_dbg) (void) hipMalloc((void **) &d_dbg, n_dbg * 4); a.dbg = d_dbg; }
-    std::lock_guard<std::mutex> lk(g_mega_mutex);
+    std::lock_guard<std::mutex> lk(mega_slot(ctx->device));
     int n_wg = std::min(ctx->model.n_cu, 256);
     if (const char * e = getenv("WHISPER_AMD_MEGA_WG")) n_wg = std::max(2 * hp.n_text_head + 1, std::min(n_wg, atoi(e)));
     wa_launch_decode_mega(st->stream, a, n_wg);

@@ -8,6 +8,7 @@
 #include "wa_internal.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -94,174 +95,184 @@ void compute_probs(const float * logits, int n, const float * logprobs, float * 
 }
 
 // -------------------------------------------------------------------------------------------------
-// heuristic token-level timestamps and segment wrapping (params.token_timestamps / max_len / split_on_word).
-// Host-side post-processing of a finished segment; behavioural contract whisper.cpp:8326-8616 and 6047-6100:
-//   1. tokens whose timestamp guess is trusted (pt > thold_pt, ptsum > thold_ptsum, increasing) anchor the time line;
-//   2. the stretches between anchors are split in proportion to a "voice length" of each token's text;
-//   3. every text token's ends then slide to where the |PCM| energy (average over 65 samples) crosses half the local mean.
-// All arithmetic types and orders follow the reference (int64 / float / double as there), so results are identical.
+// Heuristic token-level timestamps and segment wrapping (params.token_timestamps / max_len / split_on_word): host-side
+// post-processing of a finished segment.  Behavioural contract: whisper.cpp:8326-8616 and 6047-6100 (pinned by the reference
+// engine's goldens, tests/golden/s128_token_ts.json).  Organised here as a time line over flat arrays that is built in four passes:
+//   anchors  - tokens whose own timestamp guess is trusted pin a boundary of the time line;
+//   spread   - every run of boundaries still open between two pinned ones is divided in proportion to the tokens' spoken weights;
+//   repair   - boundaries that ended up out of order are pushed forward;
+//   snap     - each text token's ends slide to where the windowed |PCM| energy crosses half of its local mean.
+// Integer / float / double types of every quantity are the contract's (int64 boundaries, float weights and energies, double
+// proportions), which is what makes the results identical.
 // -------------------------------------------------------------------------------------------------
-float voice_length(const char * text) {                      // whisper.cpp:8335-8357
-    float res = 0.0f;
-    for (const char * c = text; *c; ++c) {
-        if (*c == ' ') res += 0.01f;
-        else if (*c == ',') res += 2.00f;
-        else if (*c == '.' || *c == '!' || *c == '?') res += 3.00f;
-        else if (*c >= '0' && *c <= '9') res += 3.00f;
-        else res += 1.00f;
-    }
-    return res;
+float spoken_weight(const char * text) {
+    static const std::array<float, 256> weight_of = [] {
+        std::array<float, 256> w;
+        w.fill(1.00f);
+        w[(unsigned char) ' '] = 0.01f;
+        w[(unsigned char) ','] = 2.00f;
+        for (unsigned char c : { '.', '!', '?' }) w[c] = 3.00f;
+        for (unsigned char c = '0'; c <= '9'; ++c) w[c] = 3.00f;
+        return w;
+    }();
+    float total = 0.0f;
+    for (const unsigned char * c = (const unsigned char *) text; *c; ++c) total += weight_of[*c];
+    return total;
 }
 
-std::vector<float> signal_energy(const float * signal, int n, int hw) {      // whisper.cpp:8360-8376: mean |x| over [i - hw, i + hw]
-    std::vector<float> out(n);
+// mean |x| over the window [i - half, i + half] clipped to the signal, always divided by the full window length
+std::vector<float> signal_energy(const float * signal, int n, int half) {
+    std::vector<float> e((size_t) std::max(n, 0));
+    const float full = (float) (2 * half + 1);
     for (int i = 0; i < n; ++i) {
-        float sum = 0;
-        const int j0 = std::max(-hw, -i), j1 = std::min(hw, n - 1 - i);
-        for (int j = j0; j <= j1; ++j) sum += fabsf(signal[i + j]);
-        out[i] = sum / (2 * hw + 1);
+        const int lo = std::max(i - half, 0), hi = std::min(i + half, n - 1);
+        float acc = 0;
+        for (int k = lo; k <= hi; ++k) acc += fabsf(signal[k]);
+        e[i] = acc / full;
     }
-    return out;
+    return e;
 }
 
-int ts_to_sample(int64_t t, int64_t seg_t0, int n_samples) {                  // whisper.cpp:8378-8383
-    const int sample = (int) (((t - seg_t0) * WHISPER_SAMPLE_RATE) / 100);
-    return std::max(0, std::min(n_samples - 1, sample));
+struct token_timeline {
+    const int n;
+    const int64_t seg_lo, seg_hi;                       // the segment's own span, 10 ms units
+    std::vector<int64_t> lo, hi;                        // per token: start / end boundary
+    std::vector<float> weight;
+    const std::vector<float> & energy;
+
+    token_timeline(const std::vector<whisper_token_data> & toks, int64_t t0, int64_t t1, const std::vector<float> & en)
+        : n((int) toks.size()), seg_lo(t0), seg_hi(t1), lo(toks.size()), hi(toks.size()), weight(toks.size()), energy(en) {
+        for (int j = 0; j < n; ++j) { lo[j] = toks[j].t0; hi[j] = toks[j].t1; }
+    }
+    float energy_at(int k) const { return energy[(size_t) std::min(std::max(k, 0), (int) energy.size() - 1)]; }
+    int to_sample(int64_t t) const {
+        const int smp = (int) (((t - seg_lo) * WHISPER_SAMPLE_RATE) / 100);
+        return std::min(std::max(smp, 0), (int) energy.size() - 1);
+    }
+    int64_t to_time(int smp) const { return (100ll * smp) / WHISPER_SAMPLE_RATE + seg_lo; }
+
+    // pass 1.  `origin`, `resume`, `high_tid` live in the state: a window's segments continue the previous segment's time line.
+    void anchors(whisper_context * ctx, const std::vector<whisper_token_data> & toks, float min_pt, float min_ptsum, int64_t & origin, int64_t & resume,
+                 whisper_token & high_tid) {
+        const whisper_token beg = ctx->vocab.token_beg;
+        if (toks[0].id == beg) { lo[0] = hi[0] = lo[1] = seg_lo; origin = resume = seg_lo; high_tid = beg; }
+        else lo[0] = resume;
+        for (int j = 0; j < n; ++j) {
+            weight[j] = spoken_weight(whisper_token_to_str(ctx, toks[j].id));
+            const int64_t guess = origin + 2 * (toks[j].tid - beg);
+            const bool trusted = toks[j].pt > min_pt && toks[j].ptsum > min_ptsum && toks[j].tid > high_tid && guess <= seg_hi;
+            if (!trusted) continue;
+            if (j > 0) hi[j - 1] = guess;
+            lo[j] = guess;
+            high_tid = toks[j].tid;
+        }
+        hi[n - 2] = seg_hi;
+        lo[n - 1] = hi[n - 1] = seg_hi;
+        resume = seg_hi;
+    }
+    // pass 2: runs [first, last] whose inner boundaries are open; `last` is the next token with a pinned end (or the final token)
+    void spread() {
+        for (int first = 0; first < n;) {
+            int last = first;
+            while (last < n && hi[last] < 0) ++last;          // open = below zero (token data starts out with t0 = t1 = -1); pinned ends are times >= 0
+            if (last >= n) last = n - 1;
+            if (last > first) {
+                double total = 0.0;
+                for (int j = first; j <= last; ++j) total += weight[j];
+                const double span = (double) (hi[last] - lo[first]);
+                for (int j = first; j < last; ++j) {
+                    const int64_t cut = (int64_t) ((double) lo[j] + span * weight[j] / total);
+                    hi[j] = cut;
+                    lo[j + 1] = cut;
+                }
+            }
+            first = last + 1;
+        }
+    }
+    // pass 3
+    void repair() {
+        for (int j = 0; j + 1 < n; ++j) {
+            if (hi[j] < 0) lo[j + 1] = hi[j];
+            if (j > 0 && hi[j - 1] > lo[j]) { lo[j] = hi[j - 1]; hi[j] = std::max(lo[j], hi[j]); }
+        }
+    }
+    // pass 4, one text token: both ends move to the nearest crossing of half the mean energy of the token's neighbourhood
+    void snap(int j) {
+        const int reach = WHISPER_SAMPLE_RATE / 8, n_smp = (int) energy.size();
+        int s_lo = to_sample(lo[j]), s_hi = to_sample(hi[j]);
+        const int w_lo = std::max(s_lo - reach, 0), w_hi = std::min(s_hi + reach, n_smp);
+        float total = 0.0f;
+        for (int k = w_lo; k < w_hi; ++k) total += energy_at(k);
+        const float level = 0.5 * total / (w_hi - w_lo);
+        const auto loud = [&](int k) { return energy_at(k) > level; };
+        const auto quiet = [&](int k) { return energy_at(k) < level; };
+        int k = s_lo;
+        if (loud(k) && j > 0) {                              // speech already under way: the start moves back, but not into the previous token
+            while (k > 0 && loud(k)) --k;
+            lo[j] = to_time(k);
+            if (lo[j] < hi[j - 1]) lo[j] = hi[j - 1]; else s_lo = k;
+        } else {                                             // leading silence: the start moves forward
+            while (quiet(k) && k < s_hi) ++k;
+            s_lo = k;
+            lo[j] = to_time(k);
+        }
+        k = s_hi;
+        if (loud(k)) {                                       // still speaking at the end: it moves forward, but not into the next token
+            while (k < n_smp - 1 && loud(k)) ++k;
+            hi[j] = to_time(k);
+            if (j < n - 1 && hi[j] > lo[j + 1]) hi[j] = lo[j + 1]; else s_hi = k;
+        } else {                                             // trailing silence: the end moves back
+            while (quiet(k) && k > s_lo) --k;
+            s_hi = k;
+            hi[j] = to_time(k);
+        }
+    }
+};
+
+void token_level_timestamps(whisper_context * ctx, whisper_state * st, int i_segment, float thold_pt, float thold_ptsum) {
+    auto & seg = st->result_all[i_segment];
+    auto & toks = seg.tokens;
+    if (st->energy.empty()) { WA_ERROR("%s: no signal data available\n", __func__); return; }
+    if (toks.empty()) return;
+    if (toks.size() == 1) { toks[0].t0 = seg.t0; toks[0].t1 = seg.t1; return; }
+    token_timeline line(toks, seg.t0, seg.t1, st->energy);
+    line.anchors(ctx, toks, thold_pt, thold_ptsum, st->t_beg, st->t_last, st->tid_last);
+    line.spread();
+    line.repair();
+    for (int j = 0; j < line.n; ++j) if (toks[j].id < ctx->vocab.token_eot) line.snap(j);
+    for (int j = 0; j < line.n; ++j) { toks[j].t0 = line.lo[j]; toks[j].t1 = line.hi[j]; toks[j].vlen = line.weight[j]; }
 }
-int64_t sample_to_ts(int i_sample, int64_t seg_t0) { return (100ll * i_sample) / WHISPER_SAMPLE_RATE + seg_t0; }
 
-void token_level_timestamps(whisper_context * ctx, whisper_state * st, int i_segment, float thold_pt, float thold_ptsum) {   // whisper.cpp:8391-8616
-    auto & segment = st->result_all[i_segment];
-    auto & tokens = segment.tokens;
-    const int n_samples = (int) st->energy.size();
-    if (n_samples == 0) { WA_ERROR("%s: no signal data available\n", __func__); return; }
-    const int64_t t0 = segment.t0, t1 = segment.t1;
-    const int n = (int) tokens.size();
-    if (n == 0) return;
-    if (n == 1) { tokens[0].t0 = t0; tokens[0].t1 = t1; return; }
-    const whisper_token beg = ctx->vocab.token_beg, eot = ctx->vocab.token_eot;
-    auto & t_beg = st->t_beg; auto & t_last = st->t_last; auto & tid_last = st->tid_last;
-
-    for (int j = 0; j < n; ++j) {
-        auto & token = tokens[j];
-        if (j == 0) {
-            if (token.id == beg) {
-                tokens[j].t0 = t0; tokens[j].t1 = t0; tokens[j + 1].t0 = t0;
-                t_beg = t0; t_last = t0; tid_last = beg;
-            } else tokens[j].t0 = t_last;
-        }
-        const int64_t tt = t_beg + 2 * (token.tid - beg);
-        tokens[j].vlen = voice_length(whisper_token_to_str(ctx, token.id));
-        if (token.pt > thold_pt && token.ptsum > thold_ptsum && token.tid > tid_last && tt <= t1) {
-            if (j > 0) tokens[j - 1].t1 = tt;
-            tokens[j].t0 = tt;
-            tid_last = token.tid;
-        }
-    }
-    tokens[n - 2].t1 = t1;
-    tokens[n - 1].t0 = t1;
-    tokens[n - 1].t1 = t1;
-    t_last = t1;
-
-    {   // stretches of tokens without a trusted timestamp: split the interval by voice length
-        int p0 = 0, p1 = 0;
-        while (true) {
-            while (p1 < n && tokens[p1].t1 < 0) p1++;
-            if (p1 >= n) p1--;
-            if (p1 > p0) {
-                double psum = 0.0;
-                for (int j = p0; j <= p1; j++) psum += tokens[j].vlen;
-                const double dt = tokens[p1].t1 - tokens[p0].t0;
-                for (int j = p0 + 1; j <= p1; j++) {
-                    const double ct = tokens[j - 1].t0 + dt * tokens[j - 1].vlen / psum;
-                    tokens[j - 1].t1 = ct;
-                    tokens[j].t0 = ct;
-                }
-            }
-            p1++;
-            p0 = p1;
-            if (p1 >= n) break;
-        }
-    }
-    for (int j = 0; j < n - 1; j++) {       // fix-ups
-        if (tokens[j].t1 < 0) tokens[j + 1].t0 = tokens[j].t1;
-        if (j > 0 && tokens[j - 1].t1 > tokens[j].t0) {
-            tokens[j].t0 = tokens[j - 1].t1;
-            tokens[j].t1 = std::max(tokens[j].t0, tokens[j].t1);
-        }
-    }
-    {   // expand or contract by voice activity
-        const int hw = WHISPER_SAMPLE_RATE / 8;
-        const std::vector<float> & energy = st->energy;
-        for (int j = 0; j < n; j++) {
-            if (tokens[j].id >= eot) continue;
-            int s0 = ts_to_sample(tokens[j].t0, segment.t0, n_samples);
-            int s1 = ts_to_sample(tokens[j].t1, segment.t0, n_samples);
-            const int ss0 = std::max(s0 - hw, 0), ss1 = std::min(s1 + hw, n_samples);
-            const int ns = ss1 - ss0;
-            float sum = 0.0f;
-            for (int k = ss0; k < ss1; k++) sum += energy[k];
-            const float thold = 0.5 * sum / ns;
-            {
-                int k = s0;
-                if (energy[k] > thold && j > 0) {
-                    while (k > 0 && energy[k] > thold) k--;
-                    tokens[j].t0 = sample_to_ts(k, segment.t0);
-                    if (tokens[j].t0 < tokens[j - 1].t1) tokens[j].t0 = tokens[j - 1].t1;
-                    else s0 = k;
-                } else {
-                    while (energy[k] < thold && k < s1) k++;
-                    s0 = k;
-                    tokens[j].t0 = sample_to_ts(k, segment.t0);
-                }
-            }
-            {
-                int k = s1;
-                if (energy[k] > thold) {
-                    while (k < n_samples - 1 && energy[k] > thold) k++;
-                    tokens[j].t1 = sample_to_ts(k, segment.t0);
-                    if (j < n - 1 && tokens[j].t1 > tokens[j + 1].t0) tokens[j].t1 = tokens[j + 1].t0;
-                    else s1 = k;
-                } else {
-                    while (energy[k] < thold && k > s0) k--;
-                    s1 = k;
-                    tokens[j].t1 = sample_to_ts(k, segment.t0);
-                }
-            }
-        }
-    }
-}
-
-// wrap the last segment to max_len characters; returns the number of segments it became (whisper.cpp:6047-6100)
+// Re-cut the most recent segment so that no piece exceeds max_len characters of token text (params.max_len, split_on_word); returns
+// the number of segments it became.  Two steps: find the token positions where a new piece starts, then rebuild the pieces.
 int wrap_segment(whisper_context * ctx, whisper_state * st, int max_len, bool split_on_word) {
-    wa_segment segment = st->result_all.back();
-    int res = 1, acc = 0;
-    std::string text;
-    for (int i = 0; i < (int) segment.tokens.size(); i++) {
-        const auto & token = segment.tokens[i];
-        if (token.id >= ctx->vocab.token_eot) continue;
-        const char * txt = whisper_token_to_str(ctx, token.id);
-        const int cur = (int) strlen(txt);
-        if (acc + cur > max_len && i > 0 && (!split_on_word || txt[0] == ' ')) {
-            auto & last = st->result_all.back();
-            last.text = std::move(text);
-            last.t1 = token.t0;
-            last.tokens.resize(i);
-            last.speaker_turn_next = false;
-            wa_segment next;
-            next.t0 = token.t0; next.t1 = segment.t1;
-            next.tokens.assign(segment.tokens.begin() + i, segment.tokens.end());
-            next.speaker_turn_next = segment.speaker_turn_next;
-            st->result_all.push_back(std::move(next));
-            acc = 0;
-            text = "";
-            segment = st->result_all.back();
-            i = -1;
-            res++;
-        } else { acc += cur; text += txt; }
+    const wa_segment whole = st->result_all.back();
+    const auto & toks = whole.tokens;
+    const int n = (int) toks.size();
+    const auto printable = [&](int i) { return toks[i].id < ctx->vocab.token_eot; };
+    std::vector<int> starts = { 0 };                    // first token of every piece
+    for (int i = 0, chars = 0; i < n; ++i) {
+        if (!printable(i)) continue;
+        const char * txt = whisper_token_to_str(ctx, toks[i].id);
+        const int len = (int) strlen(txt);
+        const bool may_cut = i > starts.back() && (!split_on_word || txt[0] == ' ');
+        if (chars + len > max_len && may_cut) { starts.push_back(i); chars = 0; }
+        chars += len;
     }
-    st->result_all.back().text = std::move(text);
-    return res;
+    st->result_all.pop_back();
+    for (size_t k = 0; k < starts.size(); ++k) {
+        const int first = starts[k], last = k + 1 < starts.size() ? starts[k + 1] : n;
+        const bool final_piece = k + 1 == starts.size();
+        wa_segment piece;
+        piece.t0 = k == 0 ? whole.t0 : toks[first].t0;
+        piece.t1 = final_piece ? whole.t1 : toks[last].t0;
+        if (k == 0) piece.no_speech_prob = whole.no_speech_prob;       // (later pieces keep the default, as in the contract)
+        piece.speaker_turn_next = final_piece ? whole.speaker_turn_next : false;
+        piece.tokens.assign(toks.begin() + first, toks.begin() + last);
+        for (int i = first; i < last; ++i) if (printable(i)) piece.text += whisper_token_to_str(ctx, toks[i].id);
+        st->result_all.push_back(std::move(piece));
+    }
+    return (int) starts.size();
 }
 
 struct beam_candidate { int decoder_idx; int seek_delta; bool has_ts; wa_sequence sequence; };

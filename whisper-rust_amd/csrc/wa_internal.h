@@ -257,6 +257,7 @@ struct whisper_state {
     unsigned * d_mega_smask = nullptr;             // [n_vocab / 32 + 1] per-call suppression bits
     float * h_spec[2] = { nullptr, nullptr };      // pinned [n_vocab + 16]
     hipStream_t copy_stream = nullptr;
+    bool spec_owner = false;                 // this state holds its device's one-launch slot (wa_spec_begin .. wa_spec_end)
     hipEvent_t ev_k[2] = { nullptr, nullptr }, ev_c[2] = { nullptr, nullptr };
     int n_spec_ok = 0, n_spec_miss = 0;
 
