@@ -25,7 +25,7 @@ order = [0, 6, 1, 2, 7, 3, 4, 5]
 for l in range(L):
     for p in order:
         r = tr[l * 8 + p]
-        extra = "  scores %.2f softmax %.2f pv %.2f" % (us(r[4]), us(r[5]), us(r[6])) if p >= 6 else ""
+        extra = "  scores %.2f softmax %.2f pv %.2f gathered %.2f" % (us(r[4]), us(r[5]), us(r[6]), us(r[7])) if p >= 6 else ("  ln: sums %.2f squares %.2f" % (us(r[4]), us(r[5])) if p in (0, 2, 4) else "")
         print("L%02d %-10s in %8.2f (%4d polls)  ready %8.2f  pub %8.2f%s" % (l, names[p], us(r[0]), r[1], us(r[2]) if r[2] else 0.0, us(r[3]), extra))
 r = tr[L * 8]
 print("final      in %8.2f (%4d polls)  ready %8.2f  done %8.2f" % (us(r[0]), r[1], us(r[2]), us(r[3])))

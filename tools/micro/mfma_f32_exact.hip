@@ -36,6 +36,22 @@ __global__ void k_mfma32(const float * A, const float * B, const float * C, floa
     for (int i = 0; i < 16; ++i) D[(8 * (i / 4) + 4 * (l / 32) + (i % 4)) * 32 + (l % 32)] = acc[i];
 }
 
+// v_mfma_f32_16x16x1_4b_f32: four independent 16 x 16 blocks, K = 1 (a rank-1 update each).  Checks the layout the score kernel
+// assumes (lane l feeds block l / 16 with A row / B column l % 16; block b's result in registers 4 b .. 4 b + 3, row 4 (l / 16) + j,
+// column l % 16) and that an update is one fmaf.  nrep chained updates per block.
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+__global__ void k_mfma16x1(const float * A, const float * B, const float * C, float * D, int nrep) {
+    const int l = threadIdx.x;
+    f32x16v acc;
+    for (int b = 0; b < 4; ++b) for (int j = 0; j < 4; ++j) acc[4 * b + j] = C[b * 256 + (4 * (l / 16) + j) * 16 + (l % 16)];
+    for (int r = 0; r < nrep; ++r) {
+        const float a = A[(size_t) r * 64 + l];        // A[r][block][row]
+        const float b = B[(size_t) r * 64 + l];        // B[r][block][col]
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, acc, 0, 0, 0);
+    }
+    for (int b = 0; b < 4; ++b) for (int j = 0; j < 4; ++j) D[b * 256 + (4 * (l / 16) + j) * 16 + (l % 16)] = acc[4 * b + j];
+}
+
 static uint32_t rng_state = 12345u;
 static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
 static float half_like(int spread) {       // a value an F16 can hold: 11-bit significand, exponent within +-spread
@@ -87,6 +103,29 @@ int main() {
                    "mul+add %ld, exact-dot-per-instruction %ld\n", MN, MN, KK, mode ? "arbitrary F32" : "F16-valued", NREP * KK, n, bad_asc, bad_desc,
                    bad_nofma, bad_pair);
         }
+    }
+    {   // the 4-block K = 1 form
+        long n = 0, bad = 0;
+        for (int t = 0; t < 200; ++t) {
+            const int NR = 6;
+            std::vector<float> A(NR * 64), B(NR * 64), Cc(1024), D(1024);
+            const int spread = 1 + t % 12;
+            for (auto & v : A) v = half_like(spread);
+            for (auto & v : B) v = half_like(spread);
+            for (auto & v : Cc) v = (t & 1) ? 0.0f : any_f32(spread);
+            hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(dC, Cc.data(), Cc.size() * 4, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k_mfma16x1, dim3(1), dim3(64), 0, 0, dA, dB, dC, dD, NR);
+            hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+            for (int b = 0; b < 4; ++b) for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) {
+                float acc = Cc[b * 256 + i * 16 + j];
+                for (int r = 0; r < NR; ++r) acc = fmaf(A[r * 64 + b * 16 + i], B[r * 64 + b * 16 + j], acc);
+                uint32_t x, y; const float dv = D[b * 256 + i * 16 + j];
+                memcpy(&x, &dv, 4); memcpy(&y, &acc, 4);
+                ++n; bad += x != y;
+            }
+        }
+        printf("mfma_f32_16x16x1 (4 blocks, K = 1) chained 6 deep: %ld outputs; mismatches vs fmaf chain per block %ld\n", n, bad);
     }
     return 0;
 }

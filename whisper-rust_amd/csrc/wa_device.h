@@ -226,16 +226,22 @@ __device__ __forceinline__ float wa_expf_libm(float x) {
 // monotonic, so when (S - delta)/n and (S + delta)/n round to the SAME float, that float is the reference's
 // value whatever its order was.  Otherwise (probability ~ n 2^-27 per row) one lane redoes the sum in index order.
 // `rn` = 1.0 / (double) n, which a caller on a latency-critical path brings along (an F64 division is ~150 dependent cycles).
-__device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out, double rn) {
+__device__ __forceinline__ bool wa_sum_bounds(double S, double A, int n, float & lo, float & hi, double rn) {
     // conservative bounds of (S -+ delta)/n by multiplication (1/n in F64 is within 2^-53; the 2^-48 slack covers it):
     // if both bounds round to the same float, the correctly rounded quotient of any sum in the interval does too.
     const double delta = (2.0 * (double) n * 0x1p-53 * A + fabs(S) * 0x1p-48) * rn * 1.000001;
     const double q = S * rn;
-    const float lo = (float) (q - delta), hi = (float) (q + delta);
-    out = lo;
+    lo = (float) (q - delta); hi = (float) (q + delta);
     return lo == hi;
 }
+__device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out, double rn) { float hi; return wa_sum_bounds(S, A, n, out, hi, rn); }
 __device__ __forceinline__ bool wa_sum_certain(double S, double A, int n, float & out) { return wa_sum_certain(S, A, n, out, 1.0 / (double) n); }
+// Second level, for a MEAN only.  A mean close to zero is where the first certificate fails (floats are dense there: |mean| below
+// ~ n 2^-29 sum|x|, a few per cent of LayerNorm rows), yet the mean is read by nothing but t = x - mean.  If every element gives the same
+// float t for mean = lo and for mean = hi, it does for every mean in between - the reference's included (x - m and the rounding to
+// F32 are monotonic in m) -, and everything downstream is a function of those t.  Only a row with an element within ~2^-12 of its
+// mean still needs the in-order sum.
+__device__ __forceinline__ bool wa_mean_indifferent(float x, float lo, float hi) { return (x - lo) == (x - hi); }
 
 // In-order F64 sum of an LDS-resident row by one lane (the certificate's fallback): b128 reads pipeline, the 8-cycle
 // dependent F64 adds are all that is left (~3 us for 768 elements; the same loop over global memory took ~60 us).

@@ -60,6 +60,8 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
     if (!dev_alloc(st.d_xn,   (size_t) tpad * d)) return false;
     if (!dev_alloc(st.d_qk,   (size_t) tpad * 2 * d)) return false;
     if (!dev_alloc(st.d_vt,   (size_t) d * tpad)) return false;
+    if (ctx.exact && ctx.model.wtype == 1 && hp.n_audio_state == hp.n_audio_head * 64)      // probability buffers of the MFMA reference-order attention
+        if (!dev_alloc(st.d_attn_p, (size_t) hp.n_audio_head * tpad * tpad) || !dev_alloc(st.d_attn_pl, (size_t) hp.n_audio_head * tpad * 32)) return false;
     if (!dev_alloc(st.d_ao,   (size_t) tpad * d)) return false;
     if (!dev_alloc(st.d_ff,   (size_t) tpad * 4 * d)) return false;
     if (!dev_alloc(st.d_embd_enc,  (size_t) tpad * d)) return false;
@@ -122,7 +124,7 @@ void wa_state_release(whisper_state & st) {
     if (st.ctx) (void) hipSetDevice(st.ctx->device);
     if (st.stream) (void) hipStreamSynchronize(st.stream);
     dev_free(st.d_mel); dev_free(st.d_pcm); dev_free(st.d_mel_max);
-    dev_free(st.d_melT); dev_free(st.d_h1); dev_free(st.d_x); dev_free(st.d_xn); dev_free(st.d_qk); dev_free(st.d_vt);
+    dev_free(st.d_melT); dev_free(st.d_h1); dev_free(st.d_x); dev_free(st.d_xn); dev_free(st.d_qk); dev_free(st.d_vt); dev_free(st.d_attn_p); dev_free(st.d_attn_pl);
     dev_free(st.d_ao); dev_free(st.d_ff); dev_free(st.d_embd_enc); dev_free(st.d_embd_conv);
     dev_free(st.d_cross_k); dev_free(st.d_cross_v);
     dev_free(st.kv_self.k); dev_free(st.kv_self.v);
@@ -201,8 +203,8 @@ bool wa_mel_set(whisper_context & ctx, whisper_state & st, const float * data, i
     }
     if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
     st.mel_n_len = n_len; st.mel_n_len_org = n_len; st.mel_n_mel = n_mel;
-    if (!mel_reserve(st, (size_t) n_len * n_mel)) return false;
-    if ((size_t) n_len * n_mel)
+    if (!mel_reserve(st, std::max<size_t>((size_t) n_len * n_mel, 1))) return false;     // n_len == 0 is legal: an all-zero window
+    if ((size_t) n_len * n_mel)                                                            // (whisper.cpp:2399-2421; examples/bench/bench.cpp:82)
         if (!WA_HIP_OK(hipMemcpy(st.d_mel, data, (size_t) n_len * n_mel * sizeof(float), hipMemcpyDefault))) return false;
     return true;
 }
@@ -294,7 +296,12 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
         const auto & L = m.enc[il];
         if (exact) wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
         else       wa_launch_layernorm(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, st.d_xn, d, nullptr, 0);
-        if (exact) {   // Q | K | V row-major in one [T][3d] buffer (the FFN buffer is free here)
+        static const bool no_mfma_attn = getenv("WHISPER_AMD_NO_EXACT_MFMA") != nullptr;
+        if (exact && st.d_attn_p && T >= 128 && !no_mfma_attn) {      // reference order on the matrix cores: Q | K row-major, V transposed, P through HBM
+            wa_epi e; e.bias = L.qkv.b; e.out = st.d_qk; e.ldo = 2 * d; e.out2 = st.d_vt; e.ldo2 = tpad; e.split0 = 2 * d;
+            wa_launch_gemm_exact(s, WA_EPI_ENC_QKV, st.d_xn, d, L.qkv.w, d, T, 3 * d, d, e);
+            wa_launch_attn_exact_mfma(s, st.d_qk, 2 * d, st.d_vt, tpad, T, d, H, KQscale, st.d_attn_p, st.d_attn_pl, (T + 127) & ~127, st.d_ao, d);
+        } else if (exact) {   // Q | K | V row-major in one [T][3d] buffer (the FFN buffer is free here)
             wa_epi e; e.bias = L.qkv.b; e.out = st.d_ff; e.ldo = 3 * d;
             wa_launch_gemm_exact(s, WA_EPI_F16, st.d_xn, d, L.qkv.w, d, T, 3 * d, d, e);
             wa_launch_attn_exact(s, st.d_ff, 3 * d, st.d_ff + d, 64, 3 * d, st.d_ff + 2 * d, 64, 3 * d, H, T, T, nullptr, KQscale,

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact_mfma(const wa_f16 * __res
     if (t >= tiles_m * tiles_n) return;
     const int bm = N > M ? t % tiles_m : t / tiles_n, bn = N > M ? t / tiles_m : t % tiles_n;
     const int m0 = bm * MX_BM, n0 = bn * MX_BN;
+    A += (size_t) blockIdx.y * e.bs_a; W += (size_t) blockIdx.y * e.bs_w;       // batched launch: one problem per grid.y
 
     // this wave's four 1 KB pieces of a stage: A rows [8 wave, 8 wave + 8) and W rows [8 wave, 8 wave + 8); a piece = 4 rows x 16 slots
     const int prow = lane >> 4, pslot = lane & 15;
@@ -291,6 +292,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact_mfma(const wa_f16 * __res
         for (int j = 0; j < 4; ++j) { float v = res[j]; if (e.bias) v = v + pcol.bias; res[j] = wa_gelu_nb(v, e.gelu); }
     }
     if (on >= N) return;
+    if (EPI == WA_EPI_ATTN_PV) {       // + the n_kv % 32 leftover cells in F64, in index order (vec.cpp:221-223), then F16
+        const int np = e.aux0, nl = e.aux1;
+        const wa_f16 * vrow = W + (size_t) on * ldw + np;
+        const wa_f16 * pl = (const wa_f16 *) e.out2 + (size_t) blockIdx.y * e.bs_o2;
+        float vl[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) vl[c] = h2f(vrow[c < nl ? c : 0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = min(om + j, M - 1);
+            double sumf = (double) res[j];
+            float prod[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) prod[c] = vl[c] * h2f(pl[(size_t) m * 32 + (c < nl ? c : 0)]);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
+            if (om + j < M) ((wa_f16 *) e.out)[(size_t) (om + j) * e.ldo + blockIdx.y * 64 + on] = f2h((float) sumf);
+        }
+        return;
+    }
+    if (EPI == WA_EPI_ENC_QKV && on >= e.split0 && om + 3 < M) {      // V transposed: this lane's four rows are consecutive m - one 8-byte store
+        unsigned short h4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float v = res[j]; if (e.bias) v = v + pcol.bias; h4[j] = f2h(v); }
+        typedef unsigned mx_u2 __attribute__((ext_vector_type(2)));
+        mx_u2 pk; pk.x = (unsigned) h4[0] | ((unsigned) h4[1] << 16); pk.y = (unsigned) h4[2] | ((unsigned) h4[3] << 16);
+        *(mx_u2 *) ((wa_f16 *) e.out2 + (size_t) (on - e.split0) * e.ldo2 + om) = pk;
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = om + j;
@@ -308,12 +338,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact_mfma(const wa_f16 * __res
 }
 
 template <int EPI>
-static void gemm_exact_mfma_launch(hipStream_t s, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {
+static void gemm_exact_mfma_launch(hipStream_t s, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e, int batch = 1) {
     static bool attr_done = false;
     constexpr int lds = MX_NST * MX_STAGE_HALFS * 2;
     if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_gemm_exact_mfma<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_done = true; }
     const int grid = ((((M + MX_BM - 1) / MX_BM) * ((N + MX_BN - 1) / MX_BN) + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_gemm_exact_mfma<EPI>), dim3(grid), dim3(256), lds, s, A, lda, W, ldw, M, N, K, e);
+    hipLaunchKernelGGL((k_gemm_exact_mfma<EPI>), dim3(grid, batch), dim3(256), lds, s, A, lda, W, ldw, M, N, K, e);
 }
 
 void wa_launch_gemm_exact(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
@@ -356,10 +386,16 @@ __device__ __forceinline__ void wa_ln_stats(const float * __restrict__ xr, int d
 #pragma unroll
     for (int k = 0; k < LN_NPL; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }    // padding adds exact zeros
     s = wave_sum_d(s); a = wave_sum_d(a);
-    if (!wa_sum_certain(s, a, d, mean)) {
-        if (lane == 0) s = wa_seq_sum_lds(lrow, d, false, 0.0f);
-        s = __shfl(s, 0, WAVE);
-        mean = (float) (s / (double) d);
+    float mean_hi;
+    if (!wa_sum_bounds(s, a, d, mean, mean_hi, 1.0 / (double) d)) {      // a mean near zero: second-level certificate (wa_device.h), else in order
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < LN_NPL; ++k) if (lane + 64 * k < d) same &= wa_mean_indifferent(xv[k], mean, mean_hi);
+        if (!__all(same)) {
+            if (lane == 0) s = wa_seq_sum_lds(lrow, d, false, 0.0f);
+            s = __shfl(s, 0, WAVE);
+            mean = (float) (s / (double) d);
+        }
     }
     double s2 = 0.0;
 #pragma unroll
@@ -449,11 +485,16 @@ __device__ __forceinline__ void wa_block_layernorm(const float * __restrict__ xr
     __syncthreads();
     s = (red[0] + red[1]) + (red[2] + red[3]);
     a = (red[4] + red[5]) + (red[6] + red[7]);
-    float mean;
-    if (!wa_sum_certain(s, a, K, mean)) {          // block-uniform decision
-        if (tid == 0) red[8] = wa_seq_sum_lds(lrow, K, false, 0.0f);
-        __syncthreads();
-        mean = (float) (red[8] / (double) K);
+    float mean, mean_hi;
+    if (!wa_sum_bounds(s, a, K, mean, mean_hi, 1.0 / (double) K)) {          // block-uniform decision; second-level certificate, else in order
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < GEMV_LN_NPL; ++k) if (tid + GEMV_THREADS * k < K) same &= wa_mean_indifferent(xv[k], mean, mean_hi);
+        if (__syncthreads_and(same ? 1 : 0) == 0) {
+            if (tid == 0) red[8] = wa_seq_sum_lds(lrow, K, false, 0.0f);
+            __syncthreads();
+            mean = (float) (red[8] / (double) K);
+        }
     }
     double s2 = 0.0;
 #pragma unroll
@@ -866,6 +907,144 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
         for (int i = 0; i < RPW; ++i) partial[(pb + r0 + i) * 64 + lane] = acc[i];
         if (rs == 0 && tid < 32) p_left[pb + tid] = (np + tid < n_kv) ? p16[np + tid] : (wa_f16) 0;
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Encoder self-attention ON THE MATRIX CORES, still in reference order (T queries x T keys per head, no mask).
+//   scores   a score is vec_dot_f16 over 64 elements = 32 partial sums of TWO fmaf each, then the tree.  v_mfma_f32_16x16x1_4b_f32 does a
+//            rank-1 update (one fmaf per element: tools/micro/mfma_f32_exact.hip) of FOUR independent 16 x 16 blocks: lane group b = lane / 16
+//            feeds block b, so with each lane holding the elements 8 b .. 8 b + 7 (and 32 + ...) of its query / key row, instruction i of
+//            a step updates the partial sums {i, 8 + i, 16 + i, 24 + i} of a 16-query x 16-key tile: 16 instructions per tile, no padding
+//            (the K = 4 form would waste half its slots on a 2-long chain), and wa_tree32 is lane-local over the 8 x 16 accumulators;
+//   soft-max exactly k_attn_exact_mq's (ops.cpp:4792-4818): 16 lanes per query row = one DPP row, certified F64 total;
+//   P        F16 probabilities to HBM, [head][T][kvp] with zeros from np = T & ~31 on, the leftover cells' apart ([head][T][32]);
+//   P V      = a reference-order GEMM with K = np (k_gemm_exact_mfma, WA_EPI_ATTN_PV adds the leftovers in F64) against V^T.
+// 110 MB of P per layer travel through HBM (< 20 us); one query per block (the VALU form above) re-read K and V from L2 instead.
+// -------------------------------------------------------------------------------------------------
+#define AS_Q 16
+#define AS_THREADS 256
+typedef float as_f16v __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * __restrict__ qk, int ldqk, int d, int T, float scale, wa_f16 * __restrict__ P,
+                                                                 wa_f16 * __restrict__ p_left, int kvp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char as_smem[];
+    float * sc = (float *) as_smem;                                     // [16][kvs] scores, then exponentials
+    const int kvs = kvp + 8;                                            // row stride: the four rows of a wave land on different banks
+    __shared__ float red[AS_THREADS / 64][AS_Q];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, j0 = blockIdx.y * AS_Q;
+    const int fr = lane & 15, fb = lane >> 4;
+
+    // ---- scores: wave w takes the key tiles w, w + 4, ... ----
+    float qf[2][8];
+    {
+        const wa_f16 * qrow = qk + (size_t) min(j0 + fr, T - 1) * ldqk + h * 64 + 8 * fb;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const half8 v = *(const half8 *) (qrow + 32 * st);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[st][i] = (float) v[i];
+        }
+    }
+    const wa_f16 * kcol = qk + d + h * 64 + 8 * fb;
+    const int ntiles = (T + 15) >> 4;
+    float lmax[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    half8 kn[2];
+    {
+        const wa_f16 * kr = kcol + (size_t) min(wave * 16 + fr, T - 1) * ldqk;
+        kn[0] = *(const half8 *) kr; kn[1] = *(const half8 *) (kr + 32);
+    }
+    for (int kt = wave; kt < ntiles; kt += AS_THREADS / 64) {
+        const half8 k0 = kn[0], k1 = kn[1];
+        {   // the next tile's key rows fly behind this tile's arithmetic
+            const wa_f16 * kr = kcol + (size_t) min((kt + AS_THREADS / 64) * 16 + fr, T - 1) * ldqk;
+            kn[0] = *(const half8 *) kr; kn[1] = *(const half8 *) (kr + 32);
+        }
+        as_f16v acc[8];
+        const as_f16v zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x1f32(qf[0][i], (float) k0[i], zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x1f32(qf[1][i], (float) k1[i], acc[i], 0, 0, 0);
+        const int key = kt * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {        // partial sum r = 8 b + i sits in acc[i][4 b + j]: wa_tree32, lane-local
+            float a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (acc[i][j] + acc[i][8 + j]) + (acc[i][4 + j] + acc[i][12 + j]);
+            const float t0 = a[0] + a[4], t1 = a[1] + a[5], t2 = a[2] + a[6], t3 = a[3] + a[7];
+            const float r = ((t0 + t1) + (t2 + t3)) * scale;
+            if (key < T) { sc[(size_t) (4 * fb + j) * kvs + key] = r; lmax[j] = fmaxf(lmax[j], r); }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {            // maximum over the 16 lanes (keys) of a lane group
+        float m = lmax[j];
+        m = fmaxf(m, dpp_f32<0x128>(m)); m = fmaxf(m, dpp_f32<0x124>(m)); m = fmaxf(m, dpp_f32<0x122>(m)); m = fmaxf(m, dpp_f32<0x121>(m));
+        if (fr == 0) red[wave][4 * fb + j] = m;
+    }
+    __syncthreads();
+
+    // ---- soft-max: 16 lanes (one DPP row) per query row ----
+    const int row = tid >> 4, u = tid & 15, jq = j0 + row;
+    float * srow = sc + (size_t) row * kvs;
+    const float mx = fmaxf(fmaxf(red[0][row], red[1][row]), fmaxf(red[2][row], red[3][row]));
+    const int n8 = T & ~7, ng = n8 >> 3, np = T & ~31;
+    double ps = 0.0;
+    for (int g = u; g < ng; g += 16) {
+        float4 lo = *(const float4 *) (srow + 8 * g), hi = *(const float4 *) (srow + 8 * g + 4);
+        lo.x = wa_expf(lo.x - mx); lo.y = wa_expf(lo.y - mx); lo.z = wa_expf(lo.z - mx); lo.w = wa_expf(lo.w - mx);
+        hi.x = wa_expf(hi.x - mx); hi.y = wa_expf(hi.y - mx); hi.z = wa_expf(hi.z - mx); hi.w = wa_expf(hi.w - mx);
+        *(float4 *) (srow + 8 * g) = lo; *(float4 *) (srow + 8 * g + 4) = hi;
+        ps += (double) (((lo.x + hi.x) + (lo.z + hi.z)) + ((lo.y + hi.y) + (lo.w + hi.w)));
+    }
+    for (int c = n8 + u; c < T; c += 16) { const float ev = wa_expf_libm(srow[c] - mx); srow[c] = ev; ps += (double) ev; }
+    ps += dpp_f64<0x111>(ps); ps += dpp_f64<0x112>(ps); ps += dpp_f64<0x114>(ps); ps += dpp_f64<0x118>(ps);      // lane 15 of the row: the total
+    double tot = __shfl(ps, lane | 15, WAVE);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this row's exponentials are in LDS (same wave: in order)
+    float inv;
+    {
+        const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
+        const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
+        inv = ilo;
+        if (ilo != ihi) {                    // the order could matter: group sums and tail in index order (vec.cpp:278-305), by one lane
+            double sum = 0.0;
+            if (u == 0) {
+                for (int g = 0; g < ng; ++g) { const float * v = srow + 8 * g; sum += (double) (((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]))); }
+                for (int c = n8; c < T; ++c) sum += (double) srow[c];
+            }
+            sum = __shfl(sum, lane & ~15, WAVE);
+            inv = (float) (1.0 / sum);
+        }
+    }
+    if (jq >= T) return;
+    wa_f16 * prow = P + ((size_t) h * T + jq) * kvp;
+    wa_f16 * plrow = p_left + ((size_t) h * T + jq) * 32;
+    typedef unsigned as_u4 __attribute__((ext_vector_type(4)));
+    for (int g = u; g < (kvp >> 3); g += 16) {
+        as_u4 pk = { 0u, 0u, 0u, 0u };
+        const int c0 = 8 * g;
+        if (c0 < np) {
+            const float4 lo = *(const float4 *) (srow + c0), hi = *(const float4 *) (srow + c0 + 4);
+            pk.x = (unsigned) f2h(lo.x * inv) | ((unsigned) f2h(lo.y * inv) << 16); pk.y = (unsigned) f2h(lo.z * inv) | ((unsigned) f2h(lo.w * inv) << 16);
+            pk.z = (unsigned) f2h(hi.x * inv) | ((unsigned) f2h(hi.y * inv) << 16); pk.w = (unsigned) f2h(hi.z * inv) | ((unsigned) f2h(hi.w * inv) << 16);
+        } else {
+            for (int c = c0; c < c0 + 8 && c < T; ++c) plrow[c - np] = f2h(srow[c] * inv);      // a leftover cell: apart, P stays zero there
+        }
+        *(as_u4 *) (prow + c0) = pk;
+    }
+}
+
+void wa_launch_attn_exact_mfma(hipStream_t s, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
+                               wa_f16 * p, wa_f16 * p_left, int kvp, wa_f16 * out, int ldo) {
+    static bool attr_done = false;
+    const int lds = AS_Q * (kvp + 8) * (int) sizeof(float);
+    if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_attn_scores_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr_done = true; }
+    hipLaunchKernelGGL(k_attn_scores_mfma, dim3(n_head, (T + AS_Q - 1) / AS_Q), dim3(AS_THREADS), lds, s, qk, ldqk, d, T, scale, p, p_left, kvp);
+    const int np = T & ~31;
+    wa_epi e; e.out = out; e.ldo = ldo; e.out2 = p_left; e.bs_o2 = (long long) T * 32; e.aux0 = np; e.aux1 = T - np;
+    e.bs_a = (long long) T * kvp; e.bs_w = (long long) 64 * ldvt;
+    gemm_exact_mfma_launch<WA_EPI_ATTN_PV>(s, p, kvp, vt, ldvt, T, 64, (np + 127) & ~127, e, n_head);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -199,6 +199,8 @@ struct whisper_state {
     wa_f16 * d_xn     = nullptr;  // [tpad][d] f16 LN output / attention output (GEMM A operand)
     wa_f16 * d_qk     = nullptr;  // [tpad][2d] f16 Q | K
     wa_f16 * d_vt     = nullptr;  // [d][tpad] f16 V transposed
+    wa_f16 * d_attn_p = nullptr;  // [n_head][tpad][tpad] f16 soft-max probabilities of a layer (reference-order MFMA attention: wa_launch_attn_exact_mfma)
+    wa_f16 * d_attn_pl = nullptr; // [n_head][tpad][32] f16 probabilities of the n_kv % 32 leftover cells
     wa_f16 * d_ao     = nullptr;  // [tpad][d] f16 attention output
     wa_f16 * d_ff     = nullptr;  // [tpad][4d] f16 GELU(fc1)
     float  * d_embd_enc  = nullptr; // [tpad][d] f32 encoder output

@@ -20,6 +20,9 @@ enum wa_epi_mode {
     WA_EPI_DEC_QKV,     // n <  split0: out  f16[m][n]                        (scaled query)
                         // n <  split1: out2 f16[(row_off + m)][n - split0]   (scaled key  -> KV cell)
                         // else       : out3 f16[(row_off + m)][n - split1]   (value       -> KV cell)
+    WA_EPI_ATTN_PV,     // the P V product of reference-order attention, one head per grid.y (wa_launch_attn_exact_mfma):
+                        //   out f16[m][64 y + n] = f16(float(double(acc) + sum_{c < aux1} double(float(W[n][aux0 + c]) * float(pl[m][c]))))
+                        //   (aux0 = np = n_kv & ~31, aux1 = n_kv - np leftover cells in F64 as vec.cpp:221-223; pl = out2, 32 per row)
 };
 
 struct wa_epi {
@@ -35,20 +38,13 @@ struct wa_epi {
     int row_off = 0;
     int aux0 = 0, aux1 = 0;
     const int * dyn = nullptr;   // device {n_kv, kv_head}: when set, row_off is read from dyn[1] (graph-replayed decode step)
+    long long bs_a = 0, bs_w = 0, bs_o2 = 0;   // batched launch (grid.y = batch index y): element offsets y * bs_* added to A, W and out2
 };
 
 // C[M x N] = A[M x K] (f16, row stride lda) * W[N x K]^T (f16, row stride ldw); K % 32 == 0.
 // MFMA path (any M); rows/cols beyond M/N are neither read out of bounds (clamped) nor stored.
 void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw,
                     int M, int N, int K, const wa_epi & e);
-
-// Same contract, M <= 8: weight-streaming GEMV (LDS dot product, no MFMA) for the decode step.
-void wa_launch_gemv(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw,
-                    int M, int N, int K, const wa_epi & e);
-
-// Row gather for the logits GEMV: A_rows[i] = A[rows[i]] handled inside via `rows` (may be null).
-void wa_launch_logits(hipStream_t stream, const wa_f16 * A, int lda, const int32_t * rows, int n_rows,
-                      const wa_f16 * W, int ldw, int N, int K, float * out /*[n_rows][N]*/);
 
 // ---- log-mel ------------------------------------------------------------------------------------
 // pcm: device f32[n_samples]. mel: device f32[n_mel][n_len]. mel_max: device scratch (1 uint).
@@ -71,17 +67,6 @@ void wa_launch_enc_attn(hipStream_t stream, const wa_f16 * qk, int ldqk, const w
 void wa_launch_dec_embed(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d,
                          const wa_f16 * te, const float * pe, float * x);
 
-// masked self-attention over KV cells; mask int8 [n_tokens][n_kv] (1 = masked out)
-void wa_launch_dec_self_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kcache, const wa_f16 * vcache,
-                             int d, int n_head, int n_tokens, int n_kv, const int8_t * mask, float * scores_scratch,
-                             wa_f16 * out, int ldo);
-
-// cross-attention over the encoder K/V: kc/vc [n_head][tpad][64] for this layer.
-// qk_out (optional, DTW): f32 [n_tokens][n_head][T] softmax probabilities.
-void wa_launch_dec_cross_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kc, const wa_f16 * vc,
-                              int tpad, int T, int n_head, int n_tokens, float scale, float * scores_scratch,
-                              wa_f16 * out, int ldo, float * qk_out);
-
 // ---- reference-order kernels (wa_exact.hip): bit-identical to the reference's ggml-cpu AVX2 path ----
 void wa_launch_gemm_exact(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
                           const wa_epi & e);
@@ -95,6 +80,12 @@ void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int
                                wa_f16 * out16, int ld16, float * out32, int ld32, int8_t * qs = nullptr, float * qd = nullptr);
 // q [n_tokens][ldq] f16; K row c of head h at kbase + h*k_head_stride + c*k_row_stride (64 halfs), V likewise.
 // partial: f32 [n_tokens][n_head][32][64], p_left: f16 [n_tokens][n_head][32] (used when n_tokens*n_head < 512).
+// Reference-order self-attention of the encoder on the matrix cores (T queries = T keys of every head, no mask), bit-identical to
+// wa_launch_attn_exact: scores + soft-max by k_attn_scores_mfma into the probability buffer `p` f16 [n_head][T][kvp] (+ the leftover
+// cells' probabilities `p_left` f16 [n_head][T][32]), then P V as a batched reference-order GEMM against V^T.
+// qk [T][ldqk] (Q | K), vt [d][ldvt] (V transposed, ldvt >= kvp, finite beyond T), kvp = T rounded up to 128.
+void wa_launch_attn_exact_mfma(hipStream_t stream, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
+                               wa_f16 * p, wa_f16 * p_left, int kvp, wa_f16 * out, int ldo);
 void wa_launch_attn_exact(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
                           float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn_n_kv = nullptr,

@@ -321,98 +321,6 @@ void wa_launch_gemm(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int 
 }
 
 // =================================================================================================
-// GEMV for the decode step (M <= 8 tokens): weight-streaming, HBM-bound.  One wave per output
-// column; the F16 activations are staged once per block in LDS; each lane streams 16-byte pieces of
-// the weight row straight into VGPRs (guide: "GEMV / M <= 16 decode weights ... neither LDS nor
-// glds"), dot products by v_dot2_f32_f16 (exact products, F32 accumulate).
-// =================================================================================================
-template <int MT, int EPI>
-__global__ __launch_bounds__(256) void k_gemv_f16(const wa_f16 * __restrict__ A, int lda, const int32_t * __restrict__ rows,
-                                                  const wa_f16 * __restrict__ W, int ldw, int M, int N, int K, wa_epi e) {
-    extern __shared__ __attribute__((aligned(16))) wa_f16 xs[];   // [MT][K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kc = K >> 3;
-    for (int c = tid; c < MT * kc; c += 256) {
-        const int m = c / kc, cc = c - m * kc;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < M) {
-            const int src = rows ? rows[m] : m;
-            v = *(const uint4 *) (A + (size_t) src * lda + cc * 8);
-        }
-        *(uint4 *) (&xs[(size_t) m * K + cc * 8]) = v;
-    }
-    __syncthreads();
-
-    for (int n = blockIdx.x * 4 + wave; n < N; n += gridDim.x * 4) {
-        const wa_f16 * wrow = W + (size_t) n * ldw;
-        float acc[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-        for (int c = lane; c < kc; c += 64) {
-            const uint4 wv = *(const uint4 *) (wrow + c * 8);
-            const half2v * w2 = (const half2v *) &wv;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const uint4 xv = *(const uint4 *) (&xs[(size_t) m * K + c * 8]);
-                const half2v * x2 = (const half2v *) &xv;
-                float a = acc[m];
-                a = __builtin_amdgcn_fdot2(w2[0], x2[0], a, false);
-                a = __builtin_amdgcn_fdot2(w2[1], x2[1], a, false);
-                a = __builtin_amdgcn_fdot2(w2[2], x2[2], a, false);
-                a = __builtin_amdgcn_fdot2(w2[3], x2[3], a, false);
-                acc[m] = a;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-            if (lane == m && m < M) epi_store<EPI>(e, m, n, acc[m]);
-    }
-}
-
-template <int MT>
-static void gemv_dispatch(hipStream_t s, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
-                          int M, int N, int K, const wa_epi & e) {
-    int grid = (N + 3) / 4;
-    if (grid > 2048) grid = 2048;
-    const size_t lds = (size_t) MT * K * sizeof(wa_f16);
-#define WA_GEMV_CASE(E) case E: hipLaunchKernelGGL((k_gemv_f16<MT, E>), dim3(grid), dim3(256), lds, s, A, lda, rows, W, ldw, M, N, K, e); break;
-    switch (mode) {
-        WA_GEMV_CASE(WA_EPI_F16)
-        WA_GEMV_CASE(WA_EPI_GELU_F16)
-        WA_GEMV_CASE(WA_EPI_RESID)
-        WA_GEMV_CASE(WA_EPI_F32)
-        WA_GEMV_CASE(WA_EPI_DEC_QKV)
-        default: break;
-    }
-#undef WA_GEMV_CASE
-}
-
-static void gemv_any(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const int32_t * rows, const wa_f16 * W, int ldw,
-                     int M, int N, int K, const wa_epi & e) {
-    if (M <= 1)      gemv_dispatch<1>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
-    else if (M <= 2) gemv_dispatch<2>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
-    else if (M <= 4) gemv_dispatch<4>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
-    else             gemv_dispatch<8>(stream, mode, A, lda, rows, W, ldw, M, N, K, e);
-}
-
-void wa_launch_gemv(hipStream_t stream, wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K,
-                    const wa_epi & e) {
-    gemv_any(stream, mode, A, lda, nullptr, W, ldw, M, N, K, e);
-}
-
-void wa_launch_logits(hipStream_t stream, const wa_f16 * A, int lda, const int32_t * rows, int n_rows, const wa_f16 * W, int ldw,
-                      int N, int K, float * out) {
-    for (int r0 = 0; r0 < n_rows; r0 += 8) {
-        const int m = n_rows - r0 < 8 ? n_rows - r0 : 8;
-        wa_epi e;
-        e.out = out + (size_t) r0 * N; e.ldo = N;
-        gemv_any(stream, WA_EPI_F32, A, lda, rows ? rows + r0 : nullptr, W, ldw, m, N, K, e);
-    }
-}
-
-// =================================================================================================
 // log-mel spectrogram (whisper.cpp:3076-3276 restated for one workgroup per frame)
 //   frame -> Hann -> radix-2 decimation 400->200->100->50->25 with naive 25-point DFT leaves (same
 //   butterfly structure and table-driven twiddles as the reference, F32) -> power -> 80x201 filterbank
@@ -810,87 +718,4 @@ __global__ void k_dec_embed(const int32_t * __restrict__ tok, const int32_t * __
 void wa_launch_dec_embed(hipStream_t stream, const int32_t * tok, const int32_t * pos, int n_tokens, int d, const wa_f16 * te,
                          const float * pe, float * x) {
     hipLaunchKernelGGL(k_dec_embed, dim3(n_tokens), dim3(256), 0, stream, tok, pos, n_tokens, d, te, pe, x);
-}
-
-// One (token, head) per block: scores over n_kv keys (F16 q . F16 k, F32 acc) -> F32 softmax with
-// optional mask -> F16 probabilities -> P V (F32 acc) -> F16.  (whisper.cpp:2636-2651 / 2732-2758,
-// ops.cpp:4731-4827.)  The score row lives in a global scratch so n_kv is unbounded.
-// HBM/L2-bound on K and V (2 * n_kv * 128 B per block).
-__global__ __launch_bounds__(256) void k_dec_attn(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
-                                                  int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
-                                                  int n_kv, const int8_t * __restrict__ mask, float scale, float * __restrict__ scratch,
-                                                  int scratch_ld, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out) {
-    __shared__ float qs[64];
-    __shared__ float red[8];
-    __shared__ double redd[4];
-    __shared__ float part[4][64];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = blockIdx.x, h = blockIdx.y, n_head = gridDim.y;
-    const wa_f16 * kp = kbase + (size_t) h * k_head_stride;
-    const wa_f16 * vp = vbase + (size_t) h * v_head_stride;
-    float * sc = scratch + ((size_t) j * n_head + h) * scratch_ld;
-    const int8_t * mrow = mask ? mask + (size_t) j * n_kv : nullptr;
-
-    if (tid < 64) qs[tid] = h2f(q[(size_t) j * ldq + h * 64 + tid]);
-    __syncthreads();
-
-    float lmax = -INFINITY;
-    for (int c = tid; c < n_kv; c += 256) {
-        const wa_f16 * kr = kp + (size_t) c * k_row_stride;
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint4 kv = *(const uint4 *) (kr + i * 8);
-            const wa_f16 * k8 = (const wa_f16 *) &kv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a = fmaf(h2f(k8[e]), qs[i * 8 + e], a);
-        }
-        a = a * scale;
-        if (mrow && mrow[c]) a = -INFINITY;
-        sc[c] = a;
-        lmax = fmaxf(lmax, a);
-    }
-    lmax = wave_max(lmax);
-    if (lane == 0) red[wave] = lmax;
-    __syncthreads();
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-
-    double lsum = 0.0;
-    for (int c = tid; c < n_kv; c += 256) {
-        const float e = wa_expf(sc[c] - mx);
-        sc[c] = e;
-        lsum += (double) e;
-    }
-    lsum = wave_sum_d(lsum);
-    if (lane == 0) redd[wave] = lsum;
-    __syncthreads();
-    const float inv = (float) (1.0 / (redd[0] + redd[1] + redd[2] + redd[3]));
-    for (int c = tid; c < n_kv; c += 256) {
-        const float p = sc[c] * inv;
-        if (qk_out) qk_out[((size_t) j * n_head + h) * n_kv + c] = p;
-        sc[c] = h2f(f2h(p));       // the P V product consumes F16 probabilities
-    }
-    __syncthreads();
-
-    float acc = 0.f;
-    for (int c = wave; c < n_kv; c += 4) acc = fmaf(sc[c], h2f(vp[(size_t) c * v_row_stride + lane]), acc);
-    part[wave][lane] = acc;
-    __syncthreads();
-    if (tid < 64) {
-        const float o = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        out[(size_t) j * ldo + h * 64 + tid] = f2h(o);
-    }
-}
-
-void wa_launch_dec_self_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kcache, const wa_f16 * vcache, int d, int n_head,
-                             int n_tokens, int n_kv, const int8_t * mask, float * scores_scratch, wa_f16 * out, int ldo) {
-    hipLaunchKernelGGL(k_dec_attn, dim3(n_tokens, n_head), dim3(256), 0, stream, q, ldq, kcache, (size_t) 64, d, vcache, (size_t) 64, d,
-                       n_kv, mask, 1.0f, scores_scratch, n_kv, out, ldo, (float *) nullptr);
-}
-
-void wa_launch_dec_cross_attn(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kc, const wa_f16 * vc, int tpad, int T,
-                              int n_head, int n_tokens, float scale, float * scores_scratch, wa_f16 * out, int ldo, float * qk_out) {
-    hipLaunchKernelGGL(k_dec_attn, dim3(n_tokens, n_head), dim3(256), 0, stream, q, ldq, kc, (size_t) tpad * 64, 64, vc, (size_t) tpad * 64,
-                       64, T, (const int8_t *) nullptr, scale, scores_scratch, T, out, ldo, qk_out);
 }

@@ -39,6 +39,9 @@ __device__ __forceinline__ mg_kargs mg_uniform(mg_kargs p) {
 #define MG_NW (MG_THREADS / 64)
 #define MG_NP3 4                  // LayerNorm elements per lane of one of the six gather waves: d <= 1536
 #define MG_SPIN_LIMIT 300000u     // polls (~0.5 us each) before a hand-off is declared dead
+#ifndef MG_DEFER
+#define MG_DEFER 1                // request a wave's next weights after the CU's next gather instead of right away (BIG assist re-fetches stay in place)
+#endif
 
 enum { E_QKV = 0, E_AO, E_X1, E_QC, E_AO2, E_X2, E_HF, E_X3 };
 
@@ -158,11 +161,26 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
         if (lane == 0) { lnred[q] = s; lnred[MG_NQ + q] = a; }
     }
     mg_barrier();
+    if (tslot >= 0) mg_trace(A, lane == 0, tslot + 4, mg_now());
     float mean = 0.0f;
+    // every wave takes the same decision from the same six partial sums (the gather waves need the mean, the others the barrier count)
+    double s = ((lnred[0] + lnred[1]) + (lnred[2] + lnred[3])) + (lnred[4] + lnred[5]);
+    const double a = ((lnred[6] + lnred[7]) + (lnred[8] + lnred[9])) + (lnred[10] + lnred[11]);
+    float mean_hi;
+    bool need_seq = false;
+    if (!wa_sum_bounds(s, a, d, mean, mean_hi, A->rn_d)) {       // rare (a mean near zero): second-level certificate over all elements
+        if (q >= 0) {
+            bool same = true;
+#pragma unroll
+            for (int k = 0; k < NP3; ++k) if (i0 + lane + 64 * k < i1) same &= wa_mean_indifferent(xv[k], mean, mean_hi);
+            if (lane == 0) ((int *) (lnred + 3 * MG_NQ))[q] = __all(same) ? 1 : 0;
+        }
+        mg_barrier();
+        const int * fl = (const int *) (lnred + 3 * MG_NQ);
+        need_seq = !(fl[0] & fl[1] & fl[2] & fl[3] & fl[4] & fl[5]);
+    }
     if (q >= 0) {
-        double s = ((lnred[0] + lnred[1]) + (lnred[2] + lnred[3])) + (lnred[4] + lnred[5]);
-        const double a = ((lnred[6] + lnred[7]) + (lnred[8] + lnred[9])) + (lnred[10] + lnred[11]);
-        if (!wa_sum_certain(s, a, d, mean, A->rn_d)) {
+        if (need_seq) {
             if (lane == 0) s = wa_seq_sum_lds(xf, d, false, 0.0f);
             s = __shfl(s, 0, WAVE);
             mean = (float) (s / (double) d);
@@ -174,6 +192,7 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
         if (lane == 0) lnred[2 * MG_NQ + q] = s2;
     }
     mg_barrier();
+    if (tslot >= 0) mg_trace(A, lane == 0, tslot + 5, mg_now());
     if (q >= 0) {
         double s2 = ((lnred[12] + lnred[13]) + (lnred[14] + lnred[15])) + (lnred[16] + lnred[17]);
         float variance;
@@ -549,6 +568,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         // ---------------- P1: LayerNorm + q|k|v ----------------
         mg_ln3<NP3>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
         mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, mg_slot(wave, MG_EX_P4), lane);
+        if (MG_DEFER && l > 0 && wave == 5) t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, 0, lane);      // deferred from the previous layer's P8
         // (Wide models give a workgroup more row groups than the one per wave that is prefetched.  The waves idle in a phase then
         //  assist: they take the extra groups on demand - overwriting the rows they hold for a later phase - and fetch those again
         //  afterwards, long before that phase.  ggml-small and below: one group per wave, nothing changes.)
@@ -569,7 +589,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 }
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 0) * 8 + 3, mg_now());
-            if (own) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+            if (own && !MG_DEFER) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
             else if (assisted) t = wave == 3 ? mg_task8<NS>(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, 0, lane)
                                              : mg_task8<NS>(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
@@ -579,6 +599,9 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
         }
         mg_barrier();
+        // (MG_DEFER: a wave's next weights are requested only once the CU's NEXT gather is over - a poll queued behind 24-48 KB of
+        //  weight loads waits for them: hand-off-1to1 costs 0.8 us with quiet endpoints, 2.3-3.5 behind 8-15 streaming waves.)
+        if (MG_DEFER && (wave == 1 || wave == 2)) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
         if (wave == 3 || (BIG && wave == 5)) {        // wave 5 assists (it holds this layer's FC2 rows, next needed in P8)
             const bool own = !BIG || wave == 3;
             bool assisted = false;
@@ -590,11 +613,12 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 1) * 8 + 3, mg_now());
-            if (own) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+            if (own && !MG_DEFER) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
             else if (assisted) t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
         mg_ln3<NP3>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
+        if (MG_DEFER && wave == 3) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, mg_slot(wave, MG_EX_P7), lane);
         if (wave == 4 || (BIG && wave == 3)) {        // wave 3 assists (it holds this layer's cross-attention output rows, next needed in P6)
             const bool own = !BIG || wave == 4;
@@ -607,7 +631,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
-            if (own) {
+            if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
                 else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
             } else if (assisted) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -618,6 +642,10 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
         }
         mg_barrier();
+        if (MG_DEFER && wave == 4) {
+            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+        }
         if (wave == 3 || (BIG && wave == 4)) {        // wave 4 assists (it holds the next layer's cross-query rows)
             const bool own = !BIG || wave == 3;
             bool assisted = false;
@@ -629,7 +657,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
-            if (own) {
+            if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
                 else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
@@ -640,6 +668,10 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
         if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
         mg_ln3<NP3>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
+        if (MG_DEFER && wave == 3) {
+            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+        }
         if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
         else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, mg_slot(wave, MG_EX_FINAL), lane);
         if (wave == 1 || wave == 2 || (BIG && (wave == 3 || wave == 4))) {        // waves 3, 4 assist (they hold the next layer's out-projection / cross-query rows)
@@ -655,7 +687,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
-            if (own) {
+            if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
                 else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
@@ -670,6 +702,10 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
         mg_barrier();
+        if (MG_DEFER && (wave == 1 || wave == 2)) {
+            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+        }
         if (wave == 5 || (BIG && (wave == 3 || wave == 4))) {        // waves 3, 4 assist (as in P7)
             const bool own = !BIG || wave == 5;
             bool assisted = false;
@@ -681,7 +717,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 if (t.valid && (lane & 15) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 5) * 8 + 3, mg_now());
-            if (own) {
+            if (own && (!MG_DEFER || l + 1 >= L)) {
                 if (l + 1 < L) t = mg_task16<4 * NS>(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
                 else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
@@ -1098,6 +1134,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
                 if (half == 0 && lane < 8) { const int cc = 8 * (ww + 1) + lane; if (cc < nl) pleft[cc] = (wa_f16) v[4]; }
             }
             mg_barrier();
+            mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 7, mg_now());
             mg_attn_finish(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid);
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 3, mg_now());
         }
