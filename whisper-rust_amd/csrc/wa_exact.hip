@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact_mfma(const wa_f16 * __res
         const int row = 8 * wave + 4 * (p & 1) + prow;
         const int chunk = pslot ^ mx_g(row);
         goff[p] = p < 2 ? ((unsigned) min(m0 + row, M - 1) * (unsigned) lda + chunk * 8) * 2u : ((unsigned) min(n0 + row, N - 1) * (unsigned) ldw + chunk * 8) * 2u;
-        ldst[p] = (p < 2 ? 0 : MX_BM * 128) + (row - prow) * 128;      // piece base (the DMA adds lane * 16 B itself)
+        ldst[p] = (p < 2 ? 0 : MX_BM * 128) + (8 * wave + 4 * (p & 1)) * 128;      // piece base, wave-uniform (the DMA adds lane * 16 B itself)
     }
     const int nk = K >> 7;
     const __attribute__((address_space(1))) char * Ab = (const __attribute__((address_space(1))) char *) A, * Wb = (const __attribute__((address_space(1))) char *) W;
@@ -294,18 +294,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact_mfma(const wa_f16 * __res
     if (on >= N) return;
     if (EPI == WA_EPI_ATTN_PV) {       // + the n_kv % 32 leftover cells in F64, in index order (vec.cpp:221-223), then F16
         const int np = e.aux0, nl = e.aux1;
-        const wa_f16 * vrow = W + (size_t) on * ldw + np;
+        const half8 * vrow = (const half8 *) (W + (size_t) on * ldw + np);      // np % 32 == 0, ldw % 8 == 0: 16-byte aligned; 32 cells in bounds (ldw >= np + 32)
         const wa_f16 * pl = (const wa_f16 *) e.out2 + (size_t) blockIdx.y * e.bs_o2;
-        float vl[32];
+        half8 vl[4];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) vl[c] = h2f(vrow[c < nl ? c : 0]);
+        for (int c = 0; c < 4; ++c) vl[c] = vrow[c];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = min(om + j, M - 1);
+            const half8 * prow = (const half8 *) (pl + (size_t) m * 32);
+            half8 pv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pv[c] = prow[c];
             double sumf = (double) res[j];
             float prod[32];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) prod[c] = vl[c] * h2f(pl[(size_t) m * 32 + (c < nl ? c : 0)]);
+            for (int c = 0; c < 32; ++c) prod[c] = (float) vl[c >> 3][c & 7] * (float) pv[c >> 3][c & 7];
 #pragma unroll
             for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
             if (om + j < M) ((wa_f16 *) e.out)[(size_t) (om + j) * e.ldo + blockIdx.y * 64 + on] = f2h((float) sumf);
@@ -916,13 +920,13 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
 //            feeds block b, so with each lane holding the elements 8 b .. 8 b + 7 (and 32 + ...) of its query / key row, instruction i of
 //            a step updates the partial sums {i, 8 + i, 16 + i, 24 + i} of a 16-query x 16-key tile: 16 instructions per tile, no padding
 //            (the K = 4 form would waste half its slots on a 2-long chain), and wa_tree32 is lane-local over the 8 x 16 accumulators;
-//   soft-max exactly k_attn_exact_mq's (ops.cpp:4792-4818): 16 lanes per query row = one DPP row, certified F64 total;
+//   soft-max exactly k_attn_exact_mq's (ops.cpp:4792-4818): 32 lanes per query row, certified F64 total;
 //   P        F16 probabilities to HBM, [head][T][kvp] with zeros from np = T & ~31 on, the leftover cells' apart ([head][T][32]);
 //   P V      = a reference-order GEMM with K = np (k_gemm_exact_mfma, WA_EPI_ATTN_PV adds the leftovers in F64) against V^T.
 // 110 MB of P per layer travel through HBM (< 20 us); one query per block (the VALU form above) re-read K and V from L2 instead.
 // -------------------------------------------------------------------------------------------------
 #define AS_Q 16
-#define AS_THREADS 256
+#define AS_THREADS 512                                       // 8 waves: two per SIMD (the score tiles of one hide the other's loads and LDS trips)
 typedef float as_f16v __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * __restrict__ qk, int ldqk, int d, int T, float scale, wa_f16 * __restrict__ P,
@@ -967,15 +971,19 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * 
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x1f32(qf[1][i], (float) k1[i], acc[i], 0, 0, 0);
         const int key = kt * 16 + fr;
+        // partial sum r = 8 b + i sits in acc[i][4 b + j]: wa_tree32, lane-local, on 4-vectors (j = 0..3: packed F32 adds)
+        f32x4 a[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {        // partial sum r = 8 b + i sits in acc[i][4 b + j]: wa_tree32, lane-local
-            float a[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = (acc[i][j] + acc[i][8 + j]) + (acc[i][4 + j] + acc[i][12 + j]);
-            const float t0 = a[0] + a[4], t1 = a[1] + a[5], t2 = a[2] + a[6], t3 = a[3] + a[7];
-            const float r = ((t0 + t1) + (t2 + t3)) * scale;
-            if (key < T) { sc[(size_t) (4 * fb + j) * kvs + key] = r; lmax[j] = fmaxf(lmax[j], r); }
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 b0 = __builtin_shufflevector(acc[i], acc[i], 0, 1, 2, 3), b1 = __builtin_shufflevector(acc[i], acc[i], 4, 5, 6, 7);
+            const f32x4 b2 = __builtin_shufflevector(acc[i], acc[i], 8, 9, 10, 11), b3 = __builtin_shufflevector(acc[i], acc[i], 12, 13, 14, 15);
+            a[i] = (b0 + b2) + (b1 + b3);
         }
+        const f32x4 t0 = a[0] + a[4], t1 = a[1] + a[5], t2 = a[2] + a[6], t3 = a[3] + a[7];
+        const f32x4 r4 = ((t0 + t1) + (t2 + t3)) * scale;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (key < T) { sc[(size_t) (4 * fb + j) * kvs + key] = r4[j]; lmax[j] = fmaxf(lmax[j], r4[j]); }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {            // maximum over the 16 lanes (keys) of a lane group
@@ -985,22 +993,26 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * 
     }
     __syncthreads();
 
-    // ---- soft-max: 16 lanes (one DPP row) per query row ----
-    const int row = tid >> 4, u = tid & 15, jq = j0 + row;
+    // ---- soft-max: 32 lanes (two DPP rows) per query row ----
+    constexpr int LPR = AS_THREADS / AS_Q;
+    const int row = tid / LPR, u = tid % LPR, jq = j0 + row;
     float * srow = sc + (size_t) row * kvs;
-    const float mx = fmaxf(fmaxf(red[0][row], red[1][row]), fmaxf(red[2][row], red[3][row]));
+    float mx = red[0][row];
+#pragma unroll
+    for (int w = 1; w < AS_THREADS / 64; ++w) mx = fmaxf(mx, red[w][row]);
     const int n8 = T & ~7, ng = n8 >> 3, np = T & ~31;
     double ps = 0.0;
-    for (int g = u; g < ng; g += 16) {
+    for (int g = u; g < ng; g += LPR) {
         float4 lo = *(const float4 *) (srow + 8 * g), hi = *(const float4 *) (srow + 8 * g + 4);
         lo.x = wa_expf(lo.x - mx); lo.y = wa_expf(lo.y - mx); lo.z = wa_expf(lo.z - mx); lo.w = wa_expf(lo.w - mx);
         hi.x = wa_expf(hi.x - mx); hi.y = wa_expf(hi.y - mx); hi.z = wa_expf(hi.z - mx); hi.w = wa_expf(hi.w - mx);
         *(float4 *) (srow + 8 * g) = lo; *(float4 *) (srow + 8 * g + 4) = hi;
         ps += (double) (((lo.x + hi.x) + (lo.z + hi.z)) + ((lo.y + hi.y) + (lo.w + hi.w)));
     }
-    for (int c = n8 + u; c < T; c += 16) { const float ev = wa_expf_libm(srow[c] - mx); srow[c] = ev; ps += (double) ev; }
-    ps += dpp_f64<0x111>(ps); ps += dpp_f64<0x112>(ps); ps += dpp_f64<0x114>(ps); ps += dpp_f64<0x118>(ps);      // lane 15 of the row: the total
-    double tot = __shfl(ps, lane | 15, WAVE);
+    for (int c = n8 + u; c < T; c += LPR) { const float ev = wa_expf_libm(srow[c] - mx); srow[c] = ev; ps += (double) ev; }
+    ps += dpp_f64<0x111>(ps); ps += dpp_f64<0x112>(ps); ps += dpp_f64<0x114>(ps); ps += dpp_f64<0x118>(ps);      // lane 15 of a DPP row: its total
+    ps += dpp_f64<0x142, 0xa>(ps);                                                                                // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold a half-wave
+    double tot = __shfl(ps, lane | 31, WAVE);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // this row's exponentials are in LDS (same wave: in order)
     float inv;
     {
@@ -1013,7 +1025,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * 
                 for (int g = 0; g < ng; ++g) { const float * v = srow + 8 * g; sum += (double) (((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]))); }
                 for (int c = n8; c < T; ++c) sum += (double) srow[c];
             }
-            sum = __shfl(sum, lane & ~15, WAVE);
+            sum = __shfl(sum, lane & ~31, WAVE);
             inv = (float) (1.0 / sum);
         }
     }
@@ -1021,7 +1033,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * 
     wa_f16 * prow = P + ((size_t) h * T + jq) * kvp;
     wa_f16 * plrow = p_left + ((size_t) h * T + jq) * 32;
     typedef unsigned as_u4 __attribute__((ext_vector_type(4)));
-    for (int g = u; g < (kvp >> 3); g += 16) {
+    for (int g = u; g < (kvp >> 3); g += LPR) {
         as_u4 pk = { 0u, 0u, 0u, 0u };
         const int c0 = 8 * g;
         if (c0 < np) {
