@@ -182,3 +182,34 @@ def test_by_value_struct_layout_field_by_field(tmp_path):
         exe3 = str(tmp_path / "abi_ref")
         subprocess.check_call(["g++", "-std=c++17", "-DABI_HEADER=\"whisper.h\"", "-I" + ref_inc + "/include", "-I" + ref_inc + "/ggml/include", src, "-o", exe3])
         assert subprocess.check_output([exe3]).decode() == want, "the fixture no longer matches the reference header"
+
+
+def test_rust_sys_tree_builds_and_links_like_build_rs(tmp_path):
+    """f3, the Rust link path: tools/make_rust_sys_tree.sh lays out a drop-in for whisper-rs' vendored `sys/whisper.cpp`; configured and
+    built the way sys/build.rs drives CMake (hipcc as compiler = the `hipblas` feature, static libraries, install), it yields the archives
+    of build.rs' link line (sys/build.rs:275-301: whisper, ggml, ggml-base, ggml-cpu, + ggml-hip) and the two headers sys/wrapper.h
+    includes.  A C program that includes them as wrapper.h does links statically against exactly that line and runs (no GPU call)."""
+    import shutil
+    import subprocess
+    if not shutil.which("cmake") or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("cmake / hipcc not available")
+    tree = subprocess.check_output([os.path.join(ROOT, "tools", "make_rust_sys_tree.sh"), str(tmp_path)]).decode().strip()
+    assert open(os.path.join(tree, "CMakeLists.txt")).read().count('project("whisper.cpp" VERSION ') == 1        # build.rs greps this line
+    build, out = str(tmp_path / "build"), str(tmp_path / "out")
+    subprocess.check_call(["cmake", "-S", tree, "-B", build, "-DCMAKE_CXX_COMPILER=/opt/rocm/bin/hipcc", "-DCMAKE_C_COMPILER=/opt/rocm/bin/hipcc",
+                           "-DCMAKE_BUILD_TYPE=Release", "-DBUILD_SHARED_LIBS=OFF", "-DGGML_HIP=ON", "-DWHISPER_BUILD_TESTS=OFF",
+                           "-DCMAKE_INSTALL_PREFIX=" + out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", build, "--target", "install", "-j", "8"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for a in ("whisper", "ggml", "ggml-base", "ggml-cpu", "ggml-hip"):
+        assert os.path.exists(os.path.join(out, "lib", "lib%s.a" % a)), a
+    src = tmp_path / "wrapper_user.c"
+    src.write_text('#include <include/whisper.h>\n#include <ggml/include/ggml.h>\n#include <stdio.h>\n'
+                   'int main(void) { struct whisper_full_params p = whisper_full_default_params(WHISPER_SAMPLING_BEAM_SEARCH);\n'
+                   '  struct whisper_context_params c = whisper_context_default_params();\n'
+                   '  printf("%d %d %d %zu %zu %s\\n", p.beam_search.beam_size, (int) c.use_gpu, whisper_lang_id("zh"), sizeof p, sizeof c, whisper_print_system_info());\n'
+                   '  return 0; }\n')
+    exe = str(tmp_path / "wrapper_user")
+    subprocess.check_call(["gcc", str(src), "-I" + tree, "-o", exe, "-L" + os.path.join(out, "lib"), "-lwhisper", "-lggml", "-lggml-base", "-lggml-cpu",
+                           "-lggml-hip", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lpthread", "-lm", "-Wl,-rpath,/opt/rocm/lib"])
+    got = subprocess.check_output([exe]).decode().split()
+    assert got[:5] == ["5", "1", "1", "296", "48"], got

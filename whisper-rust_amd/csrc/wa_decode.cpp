@@ -385,7 +385,19 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     if (n_tokens <= 0 || n_tokens > st.dec_mpad) { WA_ERROR("%s: bad batch size %d\n", __func__, n_tokens); return false; }
     if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
 
+    // validate the batch BEFORE it takes KV cells: an error return must not leave cells allocated
+    for (int i = 0; i < n_tokens; ++i)
+        if (batch.token[i] < 0 || batch.token[i] >= n_vocab || batch.pos[i] < 0 || batch.pos[i] >= hp.n_text_ctx) {
+            WA_ERROR("%s: token %d / position %d out of range\n", __func__, batch.token[i], batch.pos[i]);
+            return false;
+        }
+    {
+        int n_rows_req = 0;
+        for (int i = 0; i < n_tokens; ++i) n_rows_req += batch.logits[i] ? 1 : 0;
+        if (n_rows_req > WA_MAX_DECODERS) { WA_ERROR("%s: too many logits rows requested (%d)\n", __func__, n_rows_req); return false; }
+    }
     auto & kv = st.kv_self;
+    if (kv.size > WA_ATT_MAXKV) { WA_ERROR("%s: %u KV cells exceed the attention kernels' limit (%d)\n", __func__, kv.size, WA_ATT_MAXKV); return false; }
     if (!wa_kv_find_slot(kv, batch)) return false;
     kv.n = std::min(kv.size, (uint32_t) std::max(1, wa_kv_cell_max(kv)));     // padding = 1 (whisper.cpp:2892-2893)
     const int n_kv = kv.n, kv_head = kv.head;

@@ -741,7 +741,7 @@ void wa_launch_im2col3(hipStream_t s, const wa_f16 * src, int src_ld, int row0, 
 // them in the block and finishes in LDS (encoder: thousands of blocks); RS == 4 spreads them over 4 blocks
 // per (query, head) to put more CUs on a single decode token and leaves the tree to k_attn_combine.
 // =================================================================================================
-#define ATT_MAXKV 4096
+#define ATT_MAXKV WA_ATT_MAXKV      // static LDS of k_attn_exact (scores, probabilities): every caller checks n_kv against it
 #define ATT_THREADS 512
 #define ATT_KB 6            // keys per lane group whose K loads are issued together
 

@@ -6,6 +6,8 @@
 
 typedef uint16_t wa_f16;
 
+#define WA_ATT_MAXKV 5120        // most KV cells one attention launch may see: 512 cells x (8 decoders + 2), whisper.cpp:7100-7106
+
 // ---- GEMM epilogue descriptor -----------------------------------------------------------------
 enum wa_epi_mode {
     WA_EPI_F16 = 0,     // out f16[m][n]            = f16((acc + bias[n]) * scale[n])

@@ -96,6 +96,13 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
             WA_ERROR("%s: invalid model (bad hparams)\n", __func__);
             return false;
         }
+        // upper bounds the kernels' fixed-size LDS and index arithmetic rely on (every real Whisper model: 1500 / 448 / <= 51866 / <= 1280)
+        if (hp.n_audio_ctx > 2048 || hp.n_text_ctx > 512 || hp.n_vocab > (1 << 20) || hp.n_audio_state > 8192 || hp.n_text_state > 8192 ||
+            hp.n_audio_layer > 256 || hp.n_text_layer > 256 || hp.n_mels > 1024) {
+            WA_ERROR("%s: model dimensions beyond what this backend supports (n_audio_ctx %d, n_text_ctx %d, n_vocab %d)\n", __func__, hp.n_audio_ctx,
+                     hp.n_text_ctx, hp.n_vocab);
+            return false;
+        }
         // ftype % 1000 names the type of the 2-D weights (whisper.cpp:1567-1573; ggml_ftype: 1 F16, 7 Q8_0, 8 Q5_0).  ftype 0 (all-F32)
         // aborts in the reference's own conv path; the other quantised formats are not built.
         const int ft = hp.ftype % 1000;
