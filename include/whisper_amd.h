@@ -490,12 +490,15 @@ WHISPER_API int whisper_amd_mega_debug(struct whisper_context * ctx, struct whis
 WHISPER_API int whisper_amd_seq_debug(struct whisper_context * ctx, struct whisper_state * state, int token, int n_past, unsigned * values_out,
                                       float * logits_out);
 
-/* Chunk-parallel transcription on ONE device: runs `n_chunks` independent whisper_full_with_state
- * jobs concurrently, each on its own state / HIP stream / host thread (the single-stream decode step is latency-bound
- * and fills a fraction of the chip, so the streams overlap).  samples[i] may be host or device pointers.
- * Returns 0 or the first non-zero per-chunk code. */
+/* Chunk-parallel transcription on ONE device (the reference's model: one state + thread per chunk, whisper.cpp:7771-7806):
+ * runs `n_chunks` independent whisper_full_with_state jobs, each on its own state / HIP stream / host thread; mel, encoder and
+ * prompts overlap on the device, and the single-token decode steps of the chunks are served in LOCK STEP - one decoder pass reads
+ * every weight row once for all chunks' tokens (F16 models; up to 8 rows per pass).  Results are those of each chunk alone.
+ * samples[i] may be host or device pointers.  Returns 0 or the first non-zero per-chunk code. */
 WHISPER_API int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state ** states, int n_chunks,
                                        struct whisper_full_params params, const float * const * samples, const int * n_samples);
+/* how the last whisper_amd_full_batch call on this context decoded: lock-step passes and the token rows they served */
+WHISPER_API void whisper_amd_batch_stats(struct whisper_context * ctx, long * steps, long * rows);
 
 #ifdef __cplusplus
 }

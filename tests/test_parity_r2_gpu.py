@@ -130,6 +130,11 @@ def test_full_batch_equals_per_chunk_reference(wrs, amd_lib, gold, gen, shape):
     for st, s in zip(states, gen.BATCH_SEEDS):
         assert _segs(st) == gold[shape]["batch"]["seed%d" % s], (shape, s)
         st.free()
+    # ... and the chunks' single-token steps really were decoded in lock step (one pass for several chunks' rows)
+    steps, rows = C.c_long(), C.c_long()
+    amd_lib.whisper_amd_batch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    amd_lib.whisper_amd_batch_stats(ctx.ptr, steps, rows)
+    assert steps.value > 50 and rows.value > 2 * steps.value, (steps.value, rows.value)
     ctx.free()
 
 

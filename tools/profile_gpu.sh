@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if "k_decode_mega" in row.get("Kernel_Name", "") and row.get("Counter_Name") == c:
                 vals.append(float(row["Counter_Value"]))
     res[c] = {"launches": len(vals), "mean": sum(vals) / len(vals) if vals else None, "min": min(vals) if vals else None, "max": max(vals) if vals else None}
-# the form bench.py reads (copy to profiles/r01_decode_step_pmc.json)
+# the form bench.py reads (copy to profiles/r02_decode_step_pmc.json)
 summary = {"kernel": "k_decode_mega (ggml-small shape, 1 token, n_past = 64)",
            "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/decode_probe.py small 20 64 0 (tools/profile_gpu.sh; one counter per pass)",
            "FETCH_SIZE_KB_per_launch": res["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_per_launch": res["WRITE_SIZE"]["mean"], "launches": res["FETCH_SIZE"]["launches"],

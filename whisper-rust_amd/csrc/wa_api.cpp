@@ -61,6 +61,9 @@ void whisper_amd_abi_sizes(size_t out[6]) {
     out[3] = offsetof(whisper_full_params, vad); out[4] = offsetof(whisper_full_params, greedy); out[5] = offsetof(whisper_full_params, language);
 }
 
+// how the last whisper_amd_full_batch call on this context decoded: lock-step passes and the token rows they served
+void whisper_amd_batch_stats(struct whisper_context * ctx, long * steps, long * rows) { if (ctx) { *steps = ctx->batch_steps; *rows = ctx->batch_rows; } }
+
 } // extern "C"
 
 // -------------------------------------------------------------------------------------------------
@@ -740,9 +743,28 @@ int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state **
     // would queue behind each other token by token: with several chunks in flight the launch sequence overlaps better.
     std::vector<char> mega(n_chunks, 0);
     if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) { mega[i] = states[i]->mega_enabled; states[i]->mega_enabled = false; }
+    // ... and where the chunks' loops ask for a plain single-token step at the same time, ONE decoder pass serves them all (wa_batcher)
+    // Groups of WHISPER_AMD_BATCH_GROUP chunks (default 4) share a pass; the groups' passes run concurrently on their own streams: a pass
+    // is a chain of short latency-bound launches, so two 4-row passes side by side finish sooner than one 8-row pass after the other.
+    static const bool no_batcher = getenv("WHISPER_AMD_NO_BATCHER") != nullptr;
+    int group = 4;
+    if (const char * g = getenv("WHISPER_AMD_BATCH_GROUP")) group = std::max(2, std::min(WA_MAX_DECODERS, atoi(g)));
+    std::vector<wa_batcher *> bats;
+    for (int i0 = 0; i0 < n_chunks && !no_batcher; i0 += group) {
+        const int n = std::min(group, n_chunks - i0);
+        wa_batcher * b = wa_batcher_create(*ctx, n);       // null for a group of one / a quantised model: those chunks decode on their own
+        bats.push_back(b);
+        for (int i = i0; i < i0 + n; ++i) states[i]->batcher = b;
+    }
     for (int i = 0; i < n_chunks; ++i)
-        th.emplace_back([&, i]() { rc[i] = whisper_full_with_state(ctx, states[i], params, samples[i], n_samples[i]); });
+        th.emplace_back([&, i]() {
+            rc[i] = whisper_full_with_state(ctx, states[i], params, samples[i], n_samples[i]);
+            wa_batcher_leave(states[i]->batcher);
+        });
     for (auto & t : th) t.join();
+    for (int i = 0; i < n_chunks; ++i) states[i]->batcher = nullptr;
+    ctx->batch_steps = ctx->batch_rows = 0;
+    for (auto * b : bats) if (b) { long st_ = 0, rw_ = 0; wa_batcher_stats(b, &st_, &rw_); ctx->batch_steps += st_; ctx->batch_rows += rw_; wa_batcher_destroy(b); }
     if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) states[i]->mega_enabled = mega[i];
     for (int r : rc) if (r != 0) return r;
     return 0;

@@ -9,6 +9,8 @@
 
 #include <cmath>
 #include <mutex>
+#include <condition_variable>
+#include <vector>
 #include <cstring>
 #include <cstdlib>
 #include <cstdio>
@@ -98,8 +100,11 @@ static void linear(hipStream_t s, bool exact, wa_epi_mode mode, const wa_f16 * A
 // rows/mask are already in d_tok/d_pos/d_rows/d_mask.  `mask` may be null (every cell < n_kv visible).
 // `dyn`: device {n_kv, kv_head}; when non-null the kernels read both from there (the captured graph is replayed with
 // different values every token) and the scalar arguments are ignored.
+// `rowp` (device, n_tokens entries): the rows are single tokens of DIFFERENT states decoded in lock step (wa_batcher below) - row m's
+// key / value go to its own state's cell and its attention reads its own state's cells and encoder K / V; activations, stream and
+// scratch are `st`'s (the batcher's private state); `kv_size` = cells per layer of every member state.
 static void decode_launch(whisper_context & ctx, whisper_state & st, int n_tokens, int n_kv, int kv_head, const int8_t * mask, int n_rows,
-                          bool save_aheads, const int * dyn = nullptr) {
+                          bool save_aheads, const int * dyn = nullptr, const wa_rowptr * rowp = nullptr, uint32_t kv_size = 0) {
     const auto & m  = ctx.model;
     const auto & hp = m.hp;
     auto & kv = st.kv_self;
@@ -111,7 +116,7 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
     wa_launch_dec_embed(s, st.d_tok, st.d_pos, n_tokens, d, m.d_te, m.d_pe, st.d_dx);
 
     const float KQscale = pow(float(64), -0.25);       // whisper.cpp:2522
-    const size_t kv_layer = (size_t) kv.size * d;
+    const size_t kv_layer = (size_t) (rowp ? kv_size : kv.size) * d;
     const size_t cross_layer = (size_t) H * st.cross_tpad * 64;
 
     for (int il = 0; il < hp.n_text_layer; ++il) {
@@ -121,10 +126,11 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
             wa_epi e; e.bias = L.qkv.b; e.scale = L.qkv.s; e.out = st.d_dq; e.ldo = d;
             e.out2 = kv.k + il * kv_layer; e.ldo2 = d; e.out3 = kv.v + il * kv_layer; e.ldo3 = d;
             e.split0 = d; e.split1 = 2 * d; e.row_off = kv_head; e.dyn = dyn;
+            e.rowp = rowp; e.rowp_off = (long long) (il * kv_layer);
             ln_linear(s, ctx.exact, WA_EPI_DEC_QKV, st.d_dx, d, L.attn_ln, hp.eps, st.d_dxn, L.qkv, n_tokens, nullptr, e);
         }
         wa_launch_attn_exact(s, st.d_dq, d, kv.k + il * kv_layer, 64, d, kv.v + il * kv_layer, 64, d, H, n_tokens, n_kv, mask, 1.0f,
-                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr, dyn);
+                             st.d_att_partial, st.d_att_pleft, st.d_dao, d, nullptr, dyn, nullptr, nullptr, nullptr, rowp, 0, (long long) (il * kv_layer));
         {
             wa_epi e; e.bias = L.out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
             linear(s, ctx.exact, WA_EPI_RESID, st.d_dao, d, L.out, n_tokens, e);
@@ -138,7 +144,8 @@ static void decode_launch(whisper_context & ctx, whisper_state & st, int n_token
         if (save_aheads && st.d_aheads_qk && il < (int) st.aheads_slot.size() && st.aheads_slot[il] >= 0)
             qk_out = st.d_aheads_qk + (size_t) st.aheads_slot[il] * n_tokens * H * T;
         wa_launch_attn_exact(s, st.d_dq, d, st.d_cross_k + il * cross_layer, (size_t) st.cross_tpad * 64, 64, st.d_cross_v + il * cross_layer,
-                             (size_t) st.cross_tpad * 64, 64, H, n_tokens, T, nullptr, KQscale, st.d_att_partial, st.d_att_pleft, st.d_dao, d, qk_out);
+                             (size_t) st.cross_tpad * 64, 64, H, n_tokens, T, nullptr, KQscale, st.d_att_partial, st.d_att_pleft, st.d_dao, d, qk_out,
+                             nullptr, nullptr, nullptr, nullptr, rowp, 1, (long long) (il * cross_layer));
         {
             wa_epi e; e.bias = L.cross_out.b; e.out = st.d_dx; e.ldo = d; e.resid = st.d_dx; e.ldr = d;
             linear(s, ctx.exact, WA_EPI_RESID, st.d_dao, d, L.cross_out, n_tokens, e);
@@ -376,6 +383,117 @@ void wa_spec_drain(whisper_context &, whisper_state & st) {
     (void) hipStreamSynchronize(st.copy_stream);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Lock-step batched decode of several independent chunks on one device (whisper_amd_full_batch; the reference's model is one state
+// + thread per chunk, whisper.cpp:7771-7806, its bench a 5-token batched decode, examples/bench/bench.cpp:110-123).  Every chunk
+// keeps running the ordinary whisper_full loop on its own host thread; where that loop asks for a plain single-token step, the
+// request goes to the batcher instead.  When every member still decoding has a request in, ONE decoder pass serves them all: each
+// weight row is read once for B tokens (bytes per step = W + B (KVx + KVs)) - the rows are the members' tokens, each
+// attending over its own state's cells and encoder K / V (wa_rowptr) - and every member gets its logits row back.  Nothing else
+// changes: sampling, KV bookkeeping and results are each member's own, bit-identical to a solo run (same kernels, same order).
+// -------------------------------------------------------------------------------------------------
+struct wa_batcher {
+    whisper_context * ctx = nullptr;
+    whisper_state * bst = nullptr;                  // private state: activations, scratch and stream of the batched pass
+    wa_rowptr * h_rowp = nullptr, * d_rowp = nullptr;
+    std::mutex m;
+    std::condition_variable cv;
+    int n_members = 0;                              // threads that may still submit
+    struct req { whisper_state * st; int token, pos, n_kv, kv_head; int result; };      // result: 0 pending, 1 logits delivered, -1 not served
+    std::vector<req *> waiting;
+    long n_steps = 0, n_rows = 0;
+};
+
+wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
+    if (ctx.model.wtype != 1 || ctx.model.n_loaded == 0 || n_members < 2) return nullptr;
+    auto * b = new wa_batcher();
+    b->ctx = &ctx; b->n_members = n_members;
+    b->bst = whisper_init_state(&ctx);
+    if (!b->bst || !WA_HIP_OK(hipHostMalloc((void **) &b->h_rowp, WA_MAX_DECODERS * sizeof(wa_rowptr))) ||
+        !WA_HIP_OK(hipMalloc((void **) &b->d_rowp, WA_MAX_DECODERS * sizeof(wa_rowptr)))) { wa_batcher_destroy(b); return nullptr; }
+    return b;
+}
+void wa_batcher_destroy(wa_batcher * b) {
+    if (!b) return;
+    if (b->bst) whisper_free_state(b->bst);
+    if (b->h_rowp) (void) hipHostFree(b->h_rowp);
+    if (b->d_rowp) (void) hipFree(b->d_rowp);
+    delete b;
+}
+void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows) { if (b) { *steps = b->n_steps; *rows = b->n_rows; } }
+
+// all requests of `b->waiting` in one pass; called with b->m held by the thread that completed the set
+static void batcher_run(wa_batcher & b) {
+    whisper_context & ctx = *b.ctx;
+    whisper_state & bs = *b.bst;
+    const auto & hp = ctx.model.hp;
+    const int n_vocab = hp.n_vocab;
+    std::vector<wa_batcher::req *> reqs;
+    reqs.swap(b.waiting);
+    // members must agree on what the kernels take as launch-uniform: cells per layer and the audio context
+    const whisper_state & s0 = *reqs[0]->st;
+    const int T = s0.enc_n_ctx > 0 ? s0.enc_n_ctx : hp.n_audio_ctx;
+    std::vector<wa_batcher::req *> run;
+    for (auto * r : reqs) {
+        const whisper_state & s = *r->st;
+        const int Ts = s.enc_n_ctx > 0 ? s.enc_n_ctx : hp.n_audio_ctx;
+        if ((int) run.size() < WA_MAX_DECODERS && s.kv_self.size == s0.kv_self.size && Ts == T && s.cross_tpad == bs.cross_tpad) run.push_back(r);
+        else r->result = -1;                        // decoded by its own thread the ordinary way
+    }
+    const int B = (int) run.size();
+    bool ok = WA_HIP_OK(hipSetDevice(ctx.device));
+    if (ok) {
+        hipStream_t s = bs.stream;
+        int32_t * h_tok = bs.h_stage_i32, * h_pos = h_tok + bs.dec_mpad, * h_rows = h_pos + bs.dec_mpad;
+        int n_kv_max = 1;
+        for (int i = 0; i < B; ++i) {
+            whisper_state & ms = *run[i]->st;
+            h_tok[i] = run[i]->token; h_pos[i] = run[i]->pos; h_rows[i] = i;
+            b.h_rowp[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, run[i]->n_kv, run[i]->kv_head };
+            n_kv_max = std::max(n_kv_max, run[i]->n_kv);
+        }
+        (void) hipMemcpyAsync(bs.d_tok, h_tok, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
+        (void) hipMemcpyAsync(bs.d_pos, h_pos, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
+        (void) hipMemcpyAsync(bs.d_rows, h_rows, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
+        (void) hipMemcpyAsync(b.d_rowp, b.h_rowp, B * sizeof(wa_rowptr), hipMemcpyHostToDevice, s);
+        bs.enc_n_ctx = T;
+        decode_launch(ctx, bs, B, n_kv_max, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
+        (void) hipMemcpyAsync(bs.h_logits_pinned, bs.d_logits, (size_t) B * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
+        ok = WA_HIP_OK(hipStreamSynchronize(s));
+    }
+    for (int i = 0; i < B; ++i) {
+        if (ok) {
+            auto & lg = run[i]->st->logits;
+            lg.resize(n_vocab);
+            memcpy(lg.data(), bs.h_logits_pinned + (size_t) i * n_vocab, (size_t) n_vocab * sizeof(float));
+        }
+        run[i]->result = ok ? 1 : -1;
+    }
+    b.n_steps += 1; b.n_rows += B;
+}
+
+// a member's single-token step: 1 = logits delivered into st.logits, 0 = not served (the caller decodes it itself)
+static int batcher_step(wa_batcher & b, whisper_state & st, int token, int pos, int n_kv, int kv_head) {
+    std::unique_lock<std::mutex> lk(b.m);
+    if (b.n_members < 2) return 0;                  // the last chunk still decoding: nothing to share a pass with
+    wa_batcher::req r = { &st, token, pos, n_kv, kv_head, 0 };
+    b.waiting.push_back(&r);
+    if ((int) b.waiting.size() >= b.n_members) { batcher_run(b); b.cv.notify_all(); }
+    else b.cv.wait(lk, [&] { return r.result != 0; });
+    return r.result == 1 ? 1 : 0;
+}
+// a member is done (or failed): the others no longer wait for it
+void wa_batcher_leave(wa_batcher * b) {
+    if (!b) return;
+    std::unique_lock<std::mutex> lk(b->m);
+    b->n_members -= 1;
+    if (!b->waiting.empty() && (int) b->waiting.size() >= b->n_members) {
+        if (b->n_members >= 2 || (int) b->waiting.size() >= 2) batcher_run(*b);
+        else { for (auto * r : b->waiting) r->result = -1; b->waiting.clear(); }
+        b->cv.notify_all();
+    }
+}
+
 bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads, ggml_abort_callback abort_cb,
                void * abort_data) {
     const int64_t t0 = wa_time_us();
@@ -435,8 +553,9 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     bool need_mask = false;
     for (size_t i = 0; i < (size_t) n_tokens * n_kv && !need_mask; ++i) need_mask = h_mask[i] != 0;
     const bool steady = n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads;
-    bool done = false;
-    if (steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    bool done = false, from_batcher = false;
+    if (steady && st.batcher && m.wtype == 1) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    if (!done && steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done) {
     (void) hipMemcpyAsync(st.d_tok,  h_tok,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
     (void) hipMemcpyAsync(st.d_pos,  h_pos,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
@@ -476,6 +595,7 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     if (n_rows) (void) hipMemcpyAsync(st.h_logits_pinned, st.d_logits, (size_t) n_rows * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
     }
+    if (!from_batcher)       // (the batcher delivered its row straight into st.logits)
     for (int r = 0; r < n_rows; ++r)
         memcpy(st.logits.data() + (size_t) h_rows[r] * n_vocab, st.h_logits_pinned + (size_t) r * n_vocab, n_vocab * sizeof(float));
 

@@ -164,6 +164,11 @@ __device__ __forceinline__ void epi_apply(const wa_epi & e, int m, int n, float 
         if (e.scale) v = v * p.scale;
         const int row_off = e.dyn ? e.dyn[1] : e.row_off;
         if (n < e.split0)      ((wa_f16 *) e.out)[(size_t) m * e.ldo + n] = f2h(v);
+        else if (e.rowp) {     // rows of different states (lock-step decode of several chunks): each into its own state's cell
+            const wa_rowptr r = e.rowp[m];
+            if (n < e.split1) (r.kv_k + e.rowp_off)[(size_t) r.kv_head * e.ldo2 + (n - e.split0)] = f2h(v);
+            else              (r.kv_v + e.rowp_off)[(size_t) r.kv_head * e.ldo3 + (n - e.split1)] = f2h(v);
+        }
         else if (n < e.split1) ((wa_f16 *) e.out2)[(size_t) (row_off + m) * e.ldo2 + (n - e.split0)] = f2h(v);
         else                   ((wa_f16 *) e.out3)[(size_t) (row_off + m) * e.ldo3 + (n - e.split1)] = f2h(v);
     }

@@ -746,13 +746,18 @@ void wa_launch_im2col3(hipStream_t s, const wa_f16 * src, int src_ld, int row0, 
 #define ATT_KB 6            // keys per lane group whose K loads are issued together
 
 template <int RS>
-__global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * __restrict__ kbase, size_t k_head_stride,
-                                                            int k_row_stride, const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride,
+__global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __restrict__ q, int ldq, const wa_f16 * kbase, size_t k_head_stride,
+                                                            int k_row_stride, const wa_f16 * vbase, size_t v_head_stride, int v_row_stride,
                                                             int n_kv_arg, const int8_t * __restrict__ mask, float scale, float * __restrict__ partial,
                                                             wa_f16 * __restrict__ p_left, wa_f16 * __restrict__ out, int ldo, float * __restrict__ qk_out,
                                                             const int * __restrict__ dyn, float * __restrict__ out32, int8_t * __restrict__ q8,
-                                                            float * __restrict__ q8d) {
+                                                            float * __restrict__ q8d, const wa_rowptr * __restrict__ rowp, int rowp_cross, long long rowp_off) {
     constexpr int NW = ATT_THREADS / 64;
+    if (rowp) {        // query row j belongs to its own state: that state's cells (self) or encoder K / V (cross)
+        const wa_rowptr r = rowp[blockIdx.y];
+        kbase = (rowp_cross ? r.cross_k : r.kv_k) + rowp_off; vbase = (rowp_cross ? r.cross_v : r.kv_v) + rowp_off;
+        if (!rowp_cross) n_kv_arg = r.n_kv;
+    }
     const int n_kv = dyn ? dyn[0] : n_kv_arg;
     __shared__ float sc[ATT_MAXKV];
     __shared__ wa_f16 p16[ATT_MAXKV];
@@ -1261,10 +1266,12 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact_mq(const wa_f16 * __
 }
 
 __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ partial, const wa_f16 * __restrict__ p_left,
-                                                     const wa_f16 * __restrict__ vbase, size_t v_head_stride, int v_row_stride, int n_kv_arg,
+                                                     const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_kv_arg,
                                                      wa_f16 * __restrict__ out, int ldo, const int * __restrict__ dyn, float * __restrict__ out32,
-                                                     int8_t * __restrict__ q8, float * __restrict__ q8d) {
+                                                     int8_t * __restrict__ q8, float * __restrict__ q8d, const wa_rowptr * __restrict__ rowp, int rowp_cross,
+                                                     long long rowp_off) {
     const int j = blockIdx.x, h = blockIdx.y, n_head = gridDim.y, dh = threadIdx.x;
+    if (rowp) { const wa_rowptr r = rowp[j]; vbase = (rowp_cross ? r.cross_v : r.kv_v) + rowp_off; if (!rowp_cross) n_kv_arg = r.n_kv; }
     const int n_kv = dyn ? dyn[0] : n_kv_arg;
     const size_t pb = ((size_t) j * n_head + h) * 32;
     float s32[32];
@@ -1289,11 +1296,11 @@ __global__ __launch_bounds__(64) void k_attn_combine(const float * __restrict__ 
 void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
                           float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn, float * out32,
-                          int8_t * q8, float * q8d) {
+                          int8_t * q8, float * q8d, const wa_rowptr * rowp, int rowp_cross, long long rowp_off) {
     // few (token, head) pairs and a long key range (decode cross-attention): spread the 32 partial-sum chains over 4 blocks
     // per pair and finish in k_attn_combine; otherwise one block per pair finishes in LDS (encoder, prompt, self-attention)
     const bool split = (long) n_tokens * n_head < 512 && n_kv > 512;
-    if (!split && !dyn && n_tokens >= 4 && n_kv <= 2048 && (long) ((n_tokens + 3) / 4) * n_head >= 256) {
+    if (!split && !dyn && !rowp && n_tokens >= 4 && n_kv <= 2048 && (long) ((n_tokens + 3) / 4) * n_head >= 256) {
         // enough (query, head) pairs to fill the chip four queries at a time: share the K / V loads between them
         constexpr int NQ = 4;
         const int kvp = (n_kv + 31) & ~31;
@@ -1306,11 +1313,11 @@ void wa_launch_attn_exact(hipStream_t s, const wa_f16 * q, int ldq, const wa_f16
     }
     if (!split) {
         hipLaunchKernelGGL((k_attn_exact<1>), dim3(n_head, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32, q8, q8d);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32, q8, q8d, rowp, rowp_cross, rowp_off);
     } else {
         hipLaunchKernelGGL((k_attn_exact<4>), dim3(n_head * 4, n_tokens), dim3(ATT_THREADS), 0, s, q, ldq, kbase, k_head_stride, k_row_stride, vbase,
-                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32, q8, q8d);
+                           v_head_stride, v_row_stride, n_kv, mask, scale, partial, p_left, out, ldo, qk_out, dyn, out32, q8, q8d, rowp, rowp_cross, rowp_off);
         hipLaunchKernelGGL(k_attn_combine, dim3(n_tokens, n_head), dim3(64), 0, s, partial, p_left, vbase, v_head_stride, v_row_stride, n_kv,
-                           out, ldo, dyn, out32, q8, q8d);
+                           out, ldo, dyn, out32, q8, q8d, rowp, rowp_cross, rowp_off);
     }
 }

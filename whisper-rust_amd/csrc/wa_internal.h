@@ -124,6 +124,7 @@ struct whisper_context {
     wa_vocab vocab;
     whisper_state * state = nullptr;      // default state (only for the non-_no_state constructors)
     std::string path_model;
+    long batch_steps = 0, batch_rows = 0; // the last whisper_amd_full_batch call: lock-step passes and the token rows they served
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -259,6 +260,7 @@ struct whisper_state {
     unsigned * d_mega_smask = nullptr;             // [n_vocab / 32 + 1] per-call suppression bits
     float * h_spec[2] = { nullptr, nullptr };      // pinned [n_vocab + 16]
     hipStream_t copy_stream = nullptr;
+    struct wa_batcher * batcher = nullptr;   // set while this state is a member of a whisper_amd_full_batch call (wa_decode.cpp)
     bool spec_owner = false;                 // this state holds its device's one-launch slot (wa_spec_begin .. wa_spec_end)
     hipEvent_t ev_k[2] = { nullptr, nullptr }, ev_c[2] = { nullptr, nullptr };
     int n_spec_ok = 0, n_spec_miss = 0;
@@ -307,6 +309,12 @@ bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, i
 int  wa_spec_wait  (whisper_context & ctx, whisper_state & st, int k, int * token_used);   // 0 ok (logits in st.logits row 0), 1 redo, -1 gave up
 void wa_spec_drain (whisper_context & ctx, whisper_state & st);
 void wa_spec_end   (whisper_context & ctx, whisper_state & st);
+// lock-step batched decode of the chunks of one whisper_amd_full_batch call (wa_decode.cpp)
+struct wa_batcher;
+wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members);      // null: not applicable (quantised model, one chunk)
+void wa_batcher_leave(wa_batcher * b);
+void wa_batcher_destroy(wa_batcher * b);
+void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows);
 bool wa_state_alloc(whisper_context & ctx, whisper_state & st);
 void wa_state_release(whisper_state & st);
 bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells);

@@ -27,6 +27,10 @@ enum wa_epi_mode {
                         //   (aux0 = np = n_kv & ~31, aux1 = n_kv - np leftover cells in F64 as vec.cpp:221-223; pl = out2, 32 per row)
 };
 
+// One row of a lock-step decode step over several independent chunks (wa_decode.cpp: wa_batcher): where THIS row's state keeps its
+// self K/V cells and its encoder K/V (layer 0; the kernels add the layer offset, equal for all rows), and its cell range.
+struct wa_rowptr { wa_f16 * kv_k; wa_f16 * kv_v; const wa_f16 * cross_k; const wa_f16 * cross_v; int n_kv; int kv_head; };
+
 struct wa_epi {
     const float * bias  = nullptr;
     const float * scale = nullptr;
@@ -41,6 +45,7 @@ struct wa_epi {
     int aux0 = 0, aux1 = 0;
     const int * dyn = nullptr;   // device {n_kv, kv_head}: when set, row_off is read from dyn[1] (graph-replayed decode step)
     long long bs_a = 0, bs_w = 0, bs_o2 = 0;   // batched launch (grid.y = batch index y): element offsets y * bs_* added to A, W and out2
+    const wa_rowptr * rowp = nullptr; long long rowp_off = 0;      // WA_EPI_DEC_QKV with rows of DIFFERENT states: row m's key / value go to its own cell
 };
 
 // C[M x N] = A[M x K] (f16, row stride lda) * W[N x K]^T (f16, row stride ldw); K % 32 == 0.
@@ -92,7 +97,9 @@ void wa_launch_attn_exact(hipStream_t stream, const wa_f16 * q, int ldq, const w
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
                           float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn_n_kv = nullptr,
                           float * out32 = nullptr /* when set: the result in F32 [n_tokens][ldo] instead of F16 (quantised models) */,
-                          int8_t * q8 = nullptr, float * q8d = nullptr /* when set: the F32 result as Q8_0 rows in the layout of wa_launch_quantize_q8_0 */);
+                          int8_t * q8 = nullptr, float * q8d = nullptr /* when set: the F32 result as Q8_0 rows in the layout of wa_launch_quantize_q8_0 */,
+                          const wa_rowptr * rowp = nullptr, int rowp_cross = 0, long long rowp_off = 0
+                          /* rowp: query row j reads ITS state's K / V (self cells [0, rowp[j].n_kv), or the encoder's when rowp_cross) at + rowp_off */);
 
 // ---- quantised weights (wa_quant.hip): ggml's Q5_0 / Q8_0 x Q8_0 products in the reference's AVX2 order ----
 // quantize_row_q8_0 (arch/x86/quants.c): x f32 [rows][ldx] -> qs int8 [rows][8][K/32][4] (kernel layout), qd f32 [rows][K/32] (block scale, rounded through F16)
