@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--flash-attn", type=int, default=0, help="0 = reference-order path, bit-identical to whisper.cpp CPU (default: what whisper-rs gets, "
                     "src/whisper_ctx.rs:490, and the path that meets north_star's parity bar); 1 = F16-MFMA tolerance path as the headline")
     ap.add_argument("--no-second-path", action="store_true", help="skip timing the other flash_attn setting in the same run")
+    ap.add_argument("--json-out", default=None, help="also write the JSON line to this file (profiler runs mix their log into stdout)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -353,6 +354,9 @@ def main():
                                    "host_cores": cores, "thread_sweep": {str(k): v for k, v in sweep.items()},
                                    "token_ids_identical_to_gpu": bool(same)}
         print(json.dumps(out), flush=True)
+        if args.json_out:
+            with open(args.json_out, "w") as f:
+                f.write(json.dumps(out) + "\n")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
