@@ -8,7 +8,8 @@ lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t)
 pcm = wsynth.synth_audio(480000, 0)
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 for flash in ([True, False] if len(sys.argv) < 3 else [bool(int(sys.argv[2]))]):
-    ctx = W.WhisperContext.new_with_params(wsynth.model_path(name), W.WhisperContextParameters(lib, flash_attn=flash), lib=lib)
+    mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)      # "small:q5_0" = the quantised file
+    ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib, flash_attn=flash), lib=lib)
     st = ctx.create_state(); st.pcm_to_mel(pcm); st.encode(0)
     t = time.perf_counter()
     for _ in range(iters): st.encode(0)

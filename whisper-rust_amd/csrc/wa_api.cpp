@@ -578,6 +578,32 @@ int whisper_full(struct whisper_context * ctx, struct whisper_full_params params
     if (params.vad) { WA_ERROR("%s: VAD is not supported by this backend\n", __func__); return -1; }
     return whisper_full_with_state(ctx, ctx->state, params, samples, n_samples);
 }
+// Lock-step decode groups for chunks transcribed together on one device (whisper_amd_full_batch, whisper_full_parallel): groups of
+// WHISPER_AMD_BATCH_GROUP chunks (default 4) share a decoder pass (wa_decode.cpp: wa_batcher); the groups' passes run concurrently on
+// their own streams - a pass is a chain of short latency-bound launches, so two 4-row passes side by side finish sooner than one 8-row
+// pass after the other (measured: 8 chunks 488x real time as one group, 589x as two).
+struct wa_batch_groups {
+    whisper_context * ctx;
+    std::vector<whisper_state *> members;
+    std::vector<wa_batcher *> bats;
+    wa_batch_groups(whisper_context * c, const std::vector<whisper_state *> & m) : ctx(c), members(m) {
+        static const bool off = getenv("WHISPER_AMD_NO_BATCHER") != nullptr;
+        int group = 4;
+        if (const char * g = getenv("WHISPER_AMD_BATCH_GROUP")) group = std::max(2, std::min(WA_MAX_DECODERS, atoi(g)));
+        for (size_t i0 = 0; i0 < members.size() && !off; i0 += group) {
+            const size_t n = std::min((size_t) group, members.size() - i0);
+            wa_batcher * b = wa_batcher_create(*ctx, (int) n);       // null for a group of one / a quantised model: those chunks decode on their own
+            bats.push_back(b);
+            for (size_t i = i0; i < i0 + n; ++i) members[i]->batcher = b;
+        }
+    }
+    ~wa_batch_groups() {
+        for (auto * st : members) st->batcher = nullptr;
+        ctx->batch_steps = ctx->batch_rows = 0;
+        for (auto * b : bats) if (b) { long st_ = 0, rw_ = 0; wa_batcher_stats(b, &st_, &rw_); ctx->batch_steps += st_; ctx->batch_rows += rw_; wa_batcher_destroy(b); }
+    }
+};
+
 int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples, int n_processors) {
     // ref: whisper.cpp:7736-7864: the audio is cut into n_processors equal parts, each transcribed on a state of its own (here:
     // concurrently on this device, one HIP stream each), the segment lists appended with their time offsets.  As in the reference
@@ -594,23 +620,32 @@ int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_para
     ctx->state->mega_enabled = false;               // several chunks in flight: the launch sequence overlaps better (see whisper_amd_full_batch)
     for (int i = 0; i < n_processors - 1; ++i) {
         whisper_state * st = whisper_init_state(ctx);
-        if (!st) { for (auto & w : workers) w.join(); for (auto * s2 : states) whisper_free_state(s2); ctx->state->mega_enabled = mega0; return -1; }
+        if (!st) { for (auto * s2 : states) whisper_free_state(s2); ctx->state->mega_enabled = mega0; return -1; }
         st->mega_enabled = false;
         states.push_back(st);
+    }
+    std::vector<whisper_state *> members = { ctx->state };
+    members.insert(members.end(), states.begin(), states.end());
+    {
+    wa_batch_groups groups(ctx, members);           // the parts' single-token steps in lock step (as whisper_amd_full_batch); ends with the joins
+    for (int i = 0; i < n_processors - 1; ++i) {
+        whisper_state * st = states[i];
         const int start = offset_samples + (i + 1) * n_per;
         const int n_cur = (i == n_processors - 2) ? n_samples - start : n_per;
         whisper_full_params pc = params;
         pc.offset_ms = 0; pc.print_progress = false; pc.print_realtime = false;
         pc.new_segment_callback = nullptr; pc.new_segment_callback_user_data = nullptr;
         pc.progress_callback = nullptr; pc.progress_callback_user_data = nullptr;
-        workers.emplace_back([=, &rcs]() { rcs[i + 1] = whisper_full_with_state(ctx, st, pc, samples + start, n_cur); });
+        workers.emplace_back([=, &rcs]() { rcs[i + 1] = whisper_full_with_state(ctx, st, pc, samples + start, n_cur); wa_batcher_leave(st->batcher); });
     }
     {
         whisper_full_params pc = params;
         pc.print_realtime = false;
         rcs[0] = whisper_full_with_state(ctx, ctx->state, pc, samples, offset_samples + n_per);
+        wa_batcher_leave(ctx->state->batcher);
     }
     for (auto & w : workers) w.join();
+    }
     ctx->state->mega_enabled = mega0;
     const int64_t offset_t = (int64_t) params.offset_ms / 10.0;
     for (int i = 0; i < n_processors - 1; ++i) {
@@ -743,28 +778,16 @@ int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state **
     // would queue behind each other token by token: with several chunks in flight the launch sequence overlaps better.
     std::vector<char> mega(n_chunks, 0);
     if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) { mega[i] = states[i]->mega_enabled; states[i]->mega_enabled = false; }
-    // ... and where the chunks' loops ask for a plain single-token step at the same time, ONE decoder pass serves them all (wa_batcher)
-    // Groups of WHISPER_AMD_BATCH_GROUP chunks (default 4) share a pass; the groups' passes run concurrently on their own streams: a pass
-    // is a chain of short latency-bound launches, so two 4-row passes side by side finish sooner than one 8-row pass after the other.
-    static const bool no_batcher = getenv("WHISPER_AMD_NO_BATCHER") != nullptr;
-    int group = 4;
-    if (const char * g = getenv("WHISPER_AMD_BATCH_GROUP")) group = std::max(2, std::min(WA_MAX_DECODERS, atoi(g)));
-    std::vector<wa_batcher *> bats;
-    for (int i0 = 0; i0 < n_chunks && !no_batcher; i0 += group) {
-        const int n = std::min(group, n_chunks - i0);
-        wa_batcher * b = wa_batcher_create(*ctx, n);       // null for a group of one / a quantised model: those chunks decode on their own
-        bats.push_back(b);
-        for (int i = i0; i < i0 + n; ++i) states[i]->batcher = b;
+    // ... and where the chunks' loops ask for a plain single-token step at the same time, ONE decoder pass serves a group of them
+    {
+        wa_batch_groups groups(ctx, std::vector<whisper_state *>(states, states + n_chunks));
+        for (int i = 0; i < n_chunks; ++i)
+            th.emplace_back([&, i]() {
+                rc[i] = whisper_full_with_state(ctx, states[i], params, samples[i], n_samples[i]);
+                wa_batcher_leave(states[i]->batcher);
+            });
+        for (auto & t : th) t.join();
     }
-    for (int i = 0; i < n_chunks; ++i)
-        th.emplace_back([&, i]() {
-            rc[i] = whisper_full_with_state(ctx, states[i], params, samples[i], n_samples[i]);
-            wa_batcher_leave(states[i]->batcher);
-        });
-    for (auto & t : th) t.join();
-    for (int i = 0; i < n_chunks; ++i) states[i]->batcher = nullptr;
-    ctx->batch_steps = ctx->batch_rows = 0;
-    for (auto * b : bats) if (b) { long st_ = 0, rw_ = 0; wa_batcher_stats(b, &st_, &rw_); ctx->batch_steps += st_; ctx->batch_rows += rw_; wa_batcher_destroy(b); }
     if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) states[i]->mega_enabled = mega[i];
     for (int r : rc) if (r != 0) return r;
     return 0;

@@ -402,6 +402,10 @@ struct wa_batcher {
     struct req { whisper_state * st; int token, pos, n_kv, kv_head; int result; };      // result: 0 pending, 1 logits delivered, -1 not served
     std::vector<req *> waiting;
     long n_steps = 0, n_rows = 0;
+    // the pass for B rows as a hipGraph (122 launches for ggml-small): captured on first use, replayed while T and the cell count stay
+    hipGraphExec_t graph[WA_MAX_DECODERS + 1] = {};
+    int graph_T[WA_MAX_DECODERS + 1] = {}; uint32_t graph_kv[WA_MAX_DECODERS + 1] = {};
+    bool graphs_ok = true;
 };
 
 wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
@@ -415,6 +419,7 @@ wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
 }
 void wa_batcher_destroy(wa_batcher * b) {
     if (!b) return;
+    for (auto & g : b->graph) if (g) (void) hipGraphExecDestroy(g);
     if (b->bst) whisper_free_state(b->bst);
     if (b->h_rowp) (void) hipHostFree(b->h_rowp);
     if (b->d_rowp) (void) hipFree(b->d_rowp);
@@ -457,7 +462,23 @@ static void batcher_run(wa_batcher & b) {
         (void) hipMemcpyAsync(bs.d_rows, h_rows, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(b.d_rowp, b.h_rowp, B * sizeof(wa_rowptr), hipMemcpyHostToDevice, s);
         bs.enc_n_ctx = T;
-        decode_launch(ctx, bs, B, n_kv_max, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
+        // (every row's own n_kv comes from its wa_rowptr; the launch-uniform n_kv only picks the kernel variant: <= 512 cells, one block per pair)
+        (void) n_kv_max;
+        static const bool no_graph = getenv("WHISPER_AMD_NO_GRAPH") != nullptr;
+        if (b.graphs_ok && !no_graph && (!b.graph[B] || b.graph_T[B] != T || b.graph_kv[B] != s0.kv_self.size)) {
+            if (b.graph[B]) { (void) hipGraphExecDestroy(b.graph[B]); b.graph[B] = nullptr; }
+            hipGraph_t g = nullptr;
+            if (WA_HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
+                decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
+                if (WA_HIP_OK(hipStreamEndCapture(s, &g)) && g) {
+                    if (!WA_HIP_OK(hipGraphInstantiate(&b.graph[B], g, nullptr, nullptr, 0))) b.graph[B] = nullptr;
+                    (void) hipGraphDestroy(g);
+                }
+            }
+            if (b.graph[B]) { b.graph_T[B] = T; b.graph_kv[B] = s0.kv_self.size; } else b.graphs_ok = false;
+        }
+        if (b.graph[B] && !no_graph) ok = WA_HIP_OK(hipGraphLaunch(b.graph[B], s));
+        else decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
         (void) hipMemcpyAsync(bs.h_logits_pinned, bs.d_logits, (size_t) B * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
         ok = WA_HIP_OK(hipStreamSynchronize(s));
     }
