@@ -36,6 +36,7 @@ import whisper_rs as W  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3   # f32-input MFMA = the F32 vector rate (MI355X_MICROARCH.md, Matrix cores)
 
 
 def encoder_flops(shape):
@@ -283,10 +284,15 @@ def main():
             except Exception as ex:  # extension only; never fail the headline
                 out["concurrent_chunks"] = {"error": str(ex)}
         eflops = encoder_flops(shape)
+        # the pipe the encoder's products run on: reference order = F32 MFMA (exact fmaf chains, 157.3 TFLOP/s = the F32 vector peak);
+        # flash_attn = F16 MFMA (2.5 PFLOP/s dense)
+        epeak = MFMA_F16_PEAK_TFLOPS if args.flash_attn else MFMA_F32_PEAK_TFLOPS
         out["encoder"] = {"ms_per_30s_chunk": round(enc_ms, 3), "gflop": round(eflops / 1e9, 1),
                           "achieved_tflops": round(eflops / (enc_ms * 1e-3) / 1e12, 1) if enc_ms > 0 else None,
-                          "peak_tflops": MFMA_F16_PEAK_TFLOPS,
-                          "frac": round(eflops / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if enc_ms > 0 else None,
+                          "pipe": "f16 mfma (v_mfma_f32_16x16x32_f16)" if args.flash_attn else "f32 mfma (v_mfma_f32_16x16x4_f32 / 16x16x1_4b: bitwise fmaf chains)",
+                          "peak_tflops": epeak,
+                          "frac": round(eflops / (enc_ms * 1e-3) / 1e12 / epeak, 4) if enc_ms > 0 else None,
+                          "frac_of_f16_mfma_peak": round(eflops / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if enc_ms > 0 else None,
                           "mel_ms": round(1e-3 * t_mel, 3)}
         # ---- the reference's whisper-bench protocol (examples/bench/bench.cpp: 256 single tokens, 64 batches of 5, 16 prompts of 256;
         #      SURVEY.md 8d) through the public C API, host work included - figures that do not depend on how many tokens a model decodes

@@ -324,3 +324,21 @@ def test_reference_bench_program_runs_on_the_product(tmp_path):
     err = r.stderr.decode(errors="replace")
     assert r.returncode == 0, err[-800:]
     assert "encode time" in err and "decode time" in err and "batchd time" in err and "prompt time" in err, err[-800:]
+
+
+def test_full_batch_with_chunks_that_leave_early(wrs, amd_lib, gold):
+    """Lock-step groups under membership churn: five chunks in one call (a group of four and a single), among them a 1 s input that
+    finishes after a few tokens and a 0.05 s input that is refused at once - the others must not wait for them, and every chunk's
+    result equals the reference engine's for that input alone."""
+    g1 = json.load(open(os.path.join(GOLDEN, "s128.json")))["full"]
+    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    pcms = [wsynth.synth_audio(480000, 0), wsynth.synth_audio(16000, 7), wsynth.synth_audio(480000, 1), wsynth.synth_audio(800, 7), wsynth.synth_audio(480000, 2)]
+    want = [gold["s128"]["batch"]["seed0"], g1["short_1s"], gold["s128"]["batch"]["seed1"], g1["short_0.05s"], gold["s128"]["batch"]["seed2"]]
+    for _ in range(2):                # twice: the second call reuses the states
+        states = [ctx.create_state() for _ in pcms]
+        wrs.full_batch(ctx, states, wrs.FullParams(amd_lib, 0, best_of=1, temperature_inc=0.0), pcms)
+        for i, st in enumerate(states):
+            got = _segs(st)
+            assert [(s["t0"], s["t1"], s["ids"], s["p"], s["plog"]) for s in got] == [(s["t0"], s["t1"], s["ids"], s["p"], s["plog"]) for s in want[i]], i
+            st.free()
+    ctx.free()
