@@ -306,13 +306,15 @@ def test_small_shape_properties(wrs, amd_lib):
     st.free(); ctx.free()
 
 
-@pytest.mark.parametrize("name,n_tok", [("s128", 40), ("tiny", 24), ("base", 24), ("small", 48), ("m1024", 12), ("w1280", 12)])
+@pytest.mark.parametrize("name,n_tok", [("s128", 40), ("tiny", 24), ("base", 24), ("small", 48), ("m1024", 12), ("w1280", 12),
+                                        ("s128:q5_0", 40), ("s128:q8_0", 40), ("small:q5_0", 40), ("w1280:q5_0", 12)])
 def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok, monkeypatch):
     """The single-token decoder pass as ONE persistent launch (wa_mega.hip) against the launch sequence (which the tests
     above pin to the reference): bit-identical logits token by token, over enough tokens that n_kv crosses the n % 8 and
     n % 32 boundaries of the soft-max / P V leftovers; and the one-launch path must actually be the one that ran."""
     amd_lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
-    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path(name), wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)      # "small:q5_0" = the quantised file
+    ctx = wrs.WhisperContext.new_with_params(mp, wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
     monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "1"); ref = ctx.create_state()
     monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "0"); meg = ctx.create_state()
     assert amd_lib.whisper_amd_mega_enabled(ref.ptr) == 0 and amd_lib.whisper_amd_mega_enabled(meg.ptr) == 1

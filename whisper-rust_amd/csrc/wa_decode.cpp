@@ -255,10 +255,12 @@ static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & 
     a.layers = (const wa_mega_layer *) m.d_mega_layers;
     a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
     a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu;
+    a.quant = m.wtype != 1 ? 1 : 0; a.te_d = nullptr;
+    if (a.quant) { a.te = (const wa_f16 *) m.te_q.qs; a.te_d = m.te_q.qd; }
     a.kv_k = st.kv_self.k; a.kv_v = st.kv_self.v; a.kv_layer_stride = (unsigned long long) st.kv_self.size * hp.n_text_state;
     a.cross_k = st.d_cross_k; a.cross_v = st.d_cross_v;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * st.cross_tpad * 64; a.cross_tpad = st.cross_tpad; a.T = T;
-    a.granules = st.d_mega_gr; a.edge_stride = 2 * hp.n_text_state; a.cross_gr = st.d_mega_cgr;
+    a.granules = st.d_mega_gr; a.edge_stride = 4 * hp.n_text_state; a.cross_gr = st.d_mega_cgr;      // (4 d: the quantised form hands the MLP's hidden row over in F32)
     a.logits = st.d_mega_out; a.status = st.d_mega_status; a.dbg = nullptr;
     a.token = token; a.pos = pos; a.n_kv = n_kv; a.kv_head = kv_head;
     a.spec = 0; a.rec_in = st.d_mega_rec[1]; a.rec_out = st.d_mega_rec[0]; a.n_rec = std::min(m.n_cu, 256);
@@ -720,7 +722,9 @@ extern "C" int whisper_amd_mega_debug(struct whisper_context * ctx, struct whisp
     wa_launch_decode_mega(st->stream, a, n_wg);
     if (!WA_HIP_OK(hipStreamSynchronize(st->stream))) return -3;
     if (a.dbg) { std::vector<float> h(n_dbg); (void) hipMemcpy(h.data(), d_dbg, n_dbg * 4, hipMemcpyDeviceToHost); FILE * f = fopen("gpurun_out/mega_dbg.bin", "wb"); if (f) { fwrite(h.data(), 4, n_dbg, f); fclose(f); } }
-    if (granules_out) (void) hipMemcpy(granules_out, st->d_mega_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * 2 * hp.n_text_state * 8, hipMemcpyDeviceToHost);
+    if (granules_out)      // [layer][8][2d]: the first 2d granules of every edge (the device keeps 4d per edge)
+        (void) hipMemcpy2D(granules_out, (size_t) 2 * hp.n_text_state * 8, st->d_mega_gr, (size_t) 4 * hp.n_text_state * 8, (size_t) 2 * hp.n_text_state * 8,
+                           (size_t) hp.n_text_layer * WA_MEGA_EDGES, hipMemcpyDeviceToHost);
     if (logits_out) (void) hipMemcpy(logits_out, st->d_mega_out, (size_t) hp.n_vocab * 4, hipMemcpyDeviceToHost);
     unsigned status = 0;
     (void) hipMemcpy(&status, st->d_mega_status, 4, hipMemcpyDeviceToHost);

@@ -90,7 +90,7 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
         if (st.mega_enabled) {
             // logits of the step and, right behind them, the status word: one device-to-host copy per token
             if (!dev_alloc(st.d_mega_cgr, (size_t) hp.n_text_layer * Ht * WA_MEGA_CGR)) return false;
-            if (!dev_alloc(st.d_mega_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * 2 * dt) || !dev_alloc(st.d_mega_out, (size_t) hp.n_vocab + 64)) return false;
+            if (!dev_alloc(st.d_mega_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * 4 * dt) || !dev_alloc(st.d_mega_out, (size_t) hp.n_vocab + 64)) return false;
             st.d_mega_status = (unsigned *) (st.d_mega_out + hp.n_vocab);
             if (!dev_alloc(st.d_mega_out2, (size_t) hp.n_vocab + 64) || !dev_alloc(st.d_mega_smask, (size_t) hp.n_vocab / 32 + 2)) return false;
             for (int b = 0; b < 2; ++b)

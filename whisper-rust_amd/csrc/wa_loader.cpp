@@ -449,14 +449,17 @@ bool wa_model_load(whisper_model_loader * loader, whisper_context & wctx) {
         for (int i = 0; i < Ld; ++i) {
             const auto & L = model.dec[i];
             wa_mega_layer & t = tab[i];
-            t.ln1_w = L.attn_ln.w;  t.ln1_b = L.attn_ln.b;  t.qkv_w = L.qkv.w; t.qkv_b = L.qkv.b; t.qkv_s = L.qkv.s;
-            t.out_w = L.out.w;      t.out_b = L.out.b;
-            t.ln2_w = L.cross_ln.w; t.ln2_b = L.cross_ln.b; t.cq_w = L.cross_q.w; t.cq_b = L.cross_q.b;
-            t.co_w  = L.cross_out.w; t.co_b = L.cross_out.b;
-            t.ln3_w = L.mlp_ln.w;   t.ln3_b = L.mlp_ln.b;   t.fc1_w = L.fc1.w; t.fc1_b = L.fc1.b;
-            t.fc2_w = L.fc2.w;      t.fc2_b = L.fc2.b;
+            // F16 model: the matrices; quantised model: their signed-byte quants (kernel layout) in the same fields + the block scales
+            auto W = [&](const wa_lin & l) { return QT == 1 ? l.w : (const wa_f16 *) l.qs; };
+            auto D = [&](const wa_lin & l) { return QT == 1 ? (const float *) nullptr : l.qd; };
+            t.ln1_w = L.attn_ln.w;  t.ln1_b = L.attn_ln.b;  t.qkv_w = W(L.qkv); t.qkv_b = L.qkv.b; t.qkv_s = L.qkv.s; t.qkv_d = D(L.qkv);
+            t.out_w = W(L.out);     t.out_b = L.out.b;      t.out_d = D(L.out);
+            t.ln2_w = L.cross_ln.w; t.ln2_b = L.cross_ln.b; t.cq_w = W(L.cross_q); t.cq_b = L.cross_q.b; t.cq_d = D(L.cross_q);
+            t.co_w  = W(L.cross_out); t.co_b = L.cross_out.b; t.co_d = D(L.cross_out);
+            t.ln3_w = L.mlp_ln.w;   t.ln3_b = L.mlp_ln.b;   t.fc1_w = W(L.fc1); t.fc1_b = L.fc1.b; t.fc1_d = D(L.fc1);
+            t.fc2_w = W(L.fc2);     t.fc2_b = L.fc2.b;      t.fc2_d = D(L.fc2);
         }
-        if (Ld > 0 && QT == 1) {      // (the one-launch decode step is built for F16 weights)
+        if (Ld > 0) {
             if (!WA_HIP_OK(hipMalloc(&model.d_mega_layers, tab.size() * sizeof(wa_mega_layer)))) return false;
             if (!WA_HIP_OK(hipMemcpy(model.d_mega_layers, tab.data(), tab.size() * sizeof(wa_mega_layer), hipMemcpyHostToDevice))) return false;
         }

@@ -15,6 +15,9 @@ struct wa_mega_layer {          // device-resident table, one entry per decoder 
     const wa_f16 * co_w;   const float * co_b;
     const float * ln3_w, * ln3_b; const wa_f16 * fc1_w; const float * fc1_b;
     const wa_f16 * fc2_w;  const float * fc2_b;
+    // quantised model (Q5_0 / Q8_0 files): the *_w pointers then hold the signed-byte quants in the kernel layout of wa_quant.hip
+    // ([row][lane 0..7][block][4]) and these the F32 block scales [row][block]; null for an F16 model
+    const float * qkv_d, * out_d, * cq_d, * co_d, * fc1_d, * fc2_d;
 };
 
 struct wa_mega_args {
@@ -22,6 +25,7 @@ struct wa_mega_args {
     const wa_mega_layer * layers; int n_layer, d, n_head, n_vocab; float eps;
     double rn_d;                                                                // 1.0 / (double) d (LayerNorm: keeps an F64 division off every phase)
     const wa_f16 * te; const float * pe; const float * lnf_w, * lnf_b; const wa_f16 * gelu;
+    const float * te_d; int quant;                                              // quantised model: te = quants, te_d = block scales of the token embedding
     // state
     wa_f16 * kv_k, * kv_v; unsigned long long kv_layer_stride;                  // self K/V [layer][cell][d]
     const wa_f16 * cross_k, * cross_v; unsigned long long cross_layer_stride;   // cross K/V [layer][head][tpad][64]
@@ -82,5 +86,5 @@ WA_HD inline void mg_role_of(int n, int H, int b, int & role, int & idx) {
 }
 
 // n_wg workgroups of 512 threads, every one of them resident at once (n_wg <= number of CUs; 1 workgroup per CU)
-void   wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg);
+void   wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg);      // a.quant selects the quantised-weights form of the kernel
 size_t wa_mega_lds_bytes();

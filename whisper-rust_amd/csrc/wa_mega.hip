@@ -70,6 +70,10 @@ __device__ __forceinline__ gu64 * mg_edge(mg_kargs A, int layer, int e) {
 // would make every wave wait here for the weights it has just started to prefetch - the opposite of what the prefetch is for.
 __device__ __forceinline__ void mg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// (quantised models) LDS of the quantised activation row inside the xin area: quants [4d] bytes, then the block scales
+__device__ __forceinline__ int8_t * mq_xq(wa_f16 * xin) { return (int8_t *) xin; }
+__device__ __forceinline__ float  * mq_xd(wa_f16 * xin) { return (float *) ((unsigned char *) xin + 4 * WA_MEGA_MAX_D); }
+
 // optional timeline (tools/mega_debug.py): 100 MHz wall-clock ticks of one workgroup per role, behind the cross-attention dumps
 __device__ __forceinline__ void mg_trace(mg_kargs A, bool who, int slot, unsigned v) {
     if (A->dbg && who) ((GAS unsigned *) A->dbg)[(size_t) A->n_layer * A->n_head * 5120 + slot] = v;
@@ -136,7 +140,7 @@ __device__ __forceinline__ void mg_ln_params(float (&gw)[NP3], float (&gb)[NP3],
 }
 // gw / gb: gamma and beta of THIS LayerNorm, loaded one phase ahead (a load issued here would sit, with its pointer fetch, in
 // front of the polling loads: measured 5 us per LayerNorm phase)
-template <int NP3>
+template <int NP3, bool Q = false>        // Q: the normalised row leaves as Q8_0 (quantize_row_q8_0: the next product's operand), not as F16
 __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* null: embeddings */, const float (&gw)[NP3], const float (&gb)[NP3], int q,
                                        int lane, float * xf, wa_f16 * xin, double * lnred, unsigned code, int tslot = -1, int token = 0) {
     const int d = A->d, seg = mg_ln_seg(d), i0 = q * seg, i1 = min(d, i0 + seg);
@@ -148,11 +152,21 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
             if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
 #pragma unroll
             for (int k = 0; k < NP3; ++k) xv[k] = (i0 + lane + 64 * k < i1) ? __uint_as_float(v[k]) : 0.0f;
-        } else {                                      // k_dec_embed: token embedding + positional embedding
+        } else if constexpr (!Q) {                    // k_dec_embed: token embedding + positional embedding
             const gch te = (gch) A->te + (size_t) token * d;
             const gcf pe = (gcf) A->pe + (size_t) A->pos * d;
 #pragma unroll
             for (int k = 0; k < NP3; ++k) { const int i = i0 + lane + 64 * k; xv[k] = i < i1 ? h2f(te[i]) + pe[i] : 0.0f; }
+        } else {                                      // k_dec_embed_q: the row dequantised (q * d, ggml-quants.c) + positional embedding
+            const int nb = d >> 5;
+            const GAS int8_t * tq = (const GAS int8_t *) A->te + (size_t) token * 8 * nb * 4;
+            const gcf td = (gcf) A->te_d + (size_t) token * nb;
+            const gcf pe = (gcf) A->pe + (size_t) A->pos * d;
+#pragma unroll
+            for (int k = 0; k < NP3; ++k) {
+                const int i = i0 + lane + 64 * k, b = i >> 5, el = i & 31;
+                xv[k] = i < i1 ? (float) (int) tq[(((size_t) (el >> 2)) * nb + b) * 4 + (el & 3)] * td[b] + pe[i] : 0.0f;
+            }
         }
         double s = 0.0, a = 0.0;
 #pragma unroll
@@ -210,7 +224,8 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
                 y = y * scale;
                 y = y * gw[k];
                 y = y + gb[k];
-                xin[i] = f2h(y);
+                if constexpr (Q) wa_q8_store(y, 0, i >> 5, i & 31, d >> 5, mq_xq(xin), mq_xd(xin));      // (a slot's part is whole 32-element blocks: i0, d % 32 == 0)
+                else xin[i] = f2h(y);
             }
         }
         if (tslot >= 0) mg_trace(A, lane == 0, tslot + 2, mg_now());
@@ -227,6 +242,17 @@ __device__ __forceinline__ void mg_gather_h2(mg_ctl & c, gu64 * edge, int i0, in
     if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
 #pragma unroll
     for (int k = 0; k < NPL; ++k) { const int i = i0 + lane + 64 * k; if (i < i1) dst32[i] = v[k]; }
+}
+
+// wave(s): the F32 granules [i0, i1) (whole 32-element blocks) quantised to Q8_0 into the activation row in LDS once they are all valid
+template <int NPL>
+__device__ __forceinline__ void mg_gather_q8(mg_ctl & c, gu64 * edge, int i0, int i1, int lane, wa_f16 * xin, int nb, unsigned code, mg_kargs A = nullptr,
+                                             int tslot = -1) {
+    unsigned v[NPL];
+    const unsigned sp = mg_sweep<NPL>(edge, [&](int k) { const int i = i0 + lane + 64 * k; return i < i1 ? i : -1; }, c, lane, v, code);
+    if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { const int i = i0 + lane + 64 * k; if (i < i1) wa_q8_store(__uint_as_float(v[k]), 0, i >> 5, i & 31, nb, mq_xq(xin), mq_xd(xin)); }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -331,7 +357,7 @@ __device__ __forceinline__ float mg_dot16(unsigned (&pf)[96], gch wrow, bool val
 // rows of one matrix owned by one GEMV workgroup: an even count, the same for every workgroup
 __device__ __forceinline__ int mg_rpw(int N, int nG) { const int r = (N + nG - 1) / nG; return (r + 1) & ~1; }
 
-struct mg_task { gch wrow; bool valid; int row; float bias, scale; };
+struct mg_task { gch wrow; bool valid; int row; float bias, scale; const GAS int * wl; const GAS float * dl; };      // wl / dl: quantised rows (below)
 
 template <int NS = 0>
 __device__ __forceinline__ mg_task mg_task8(unsigned (&pf)[96], const wa_f16 * W, const float * bias, const float * scale, int N, int K,
@@ -358,6 +384,114 @@ __device__ __forceinline__ mg_task mg_task16(unsigned (&pf)[96], const wa_f16 * 
     mg_pf16<NS>(pf, t.wrow, t.valid, K >> 5, 0);
     if (t.valid && (lane & 15) == 0 && bias) t.bias = ((gcf) bias)[t.row];
     return t;
+}
+
+// -------------------------------------------------------------------------------------------------
+// The same rows of a QUANTISED matrix (Q5_0 / Q8_0 files; wa_quant.hip has the contract: ggml_vec_dot_q5_0_q8_0 / q8_0_q8_0, AVX2 order).
+// A row is [lane u = 0..7][block][4] signed bytes + [block] F32 scales; the activation row sits in LDS quantised to Q8_0 in the same
+// order (xq [u][block][4], xd [block]).  Lane u chains  acc = fma(dw dx, (float) dot4(w, x), acc)  over the blocks in order; the three DPP
+// adds are hsum_float_8.  pf[0..47] = the lane's quads of the first 48 blocks it owns, pf[48..95] = their scales, loaded ahead.
+//   8 lanes per row : a lane owns every block (K = d: 24-40 blocks);  result in lanes with u == 0
+//   16 lanes per row: lanes 0-7 own the first half of the blocks, lanes 8-15 continue the SAME chains over the second half
+//                     (the running sums move over by one DPP row_shr:8): twice the registers for the long rows (K = 4d);  result in lane 8
+// -------------------------------------------------------------------------------------------------
+typedef int   mq_i4 __attribute__((ext_vector_type(4)));
+typedef float mq_f4 __attribute__((ext_vector_type(4)));
+#define MQ_PF 48
+template <int NB = 0>
+__device__ __forceinline__ void mq_pf(unsigned (&pf)[96], const GAS int * wl, const GAS float * dl, bool valid, int b0, int b1_rt) {
+    const int b1 = NB > 0 ? NB : b1_rt;
+#pragma unroll
+    for (int c = 0; c < MQ_PF / 4; ++c) {
+        if (b0 + 4 * c < b1 && valid) {
+            const mq_i4 w = *(const GAS mq_i4 *) (wl + b0 + 4 * c);
+            const mq_f4 sd = *(const GAS mq_f4 *) (dl + b0 + 4 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pf[4 * c + e] = (unsigned) w[e]; pf[MQ_PF + 4 * c + e] = __float_as_uint(sd[e]); }
+        }
+    }
+}
+// the lane's chains over its blocks [b0, b1): xq_u = this lane's quads in LDS (int per block), xd = the row's block scales in LDS
+template <int NB = 0>
+__device__ __forceinline__ float mq_chain(unsigned (&pf)[96], const GAS int * wl, const GAS float * dl, bool valid, int b0, int b1_rt, const int * xq_u,
+                                          const float * xd, float acc, bool have_first) {
+    const int b1 = NB > 0 ? NB : b1_rt;
+    for (int s0 = b0; s0 < b1; s0 += MQ_PF) {
+        if (s0 > b0 || !have_first) mq_pf<0>(pf, wl, dl, valid, s0, b1);
+#pragma unroll
+        for (int c = 0; c < MQ_PF / 4; ++c) {
+            if (s0 + 4 * c < b1) {
+                const mq_i4 x = *(const mq_i4 *) (xq_u + s0 + 4 * c);
+                const mq_f4 dx = *(const mq_f4 *) (xd + s0 + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = fmaf(__uint_as_float(pf[MQ_PF + 4 * c + e]) * dx[e], (float) __builtin_amdgcn_sdot4((int) pf[4 * c + e], x[e], 0, false), acc);
+            }
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ float mq_hsum8(float v) {
+    v = v + dpp_f32<0x104>(v);          // row_shl:4  acc[l] + acc[l+4]
+    v = v + dpp_f32<0x102>(v);          // row_shl:2
+    return v + dpp_f32<0x101>(v);       // row_shl:1
+}
+
+// task / product of either kind behind one signature (Q: quantised rows; D = the matrix's block scales)
+template <bool Q, int NS>
+__device__ __forceinline__ mg_task mg_mk8(unsigned (&pf)[96], const wa_f16 * W, const float * D, const float * bias, const float * scale, int N, int K,
+                                          int row0, int rows_wg, int grp, int lane) {
+    if constexpr (!Q) { mg_task t = mg_task8<NS>(pf, W, bias, scale, N, K, row0, rows_wg, grp, lane); t.wl = nullptr; t.dl = nullptr; return t; }
+    else {
+        mg_task t;
+        const int ri = grp * 8 + (lane >> 3), nb = K >> 5;
+        t.row = row0 + ri;
+        t.valid = ri < rows_wg && t.row < N;
+        t.wrow = nullptr;
+        t.wl = (const GAS int *) W + ((size_t) (t.valid ? t.row : 0) * 8 + (lane & 7)) * nb;
+        t.dl = (const GAS float *) D + (size_t) (t.valid ? t.row : 0) * nb;
+        t.bias = 0.0f; t.scale = 1.0f;
+        mq_pf<NS>(pf, t.wl, t.dl, t.valid, 0, nb);
+        if (t.valid && (lane & 7) == 0) { if (bias) t.bias = ((gcf) bias)[t.row]; if (scale) t.scale = ((gcf) scale)[t.row]; }
+        return t;
+    }
+}
+template <bool Q, int NS>
+__device__ __forceinline__ float mg_do8(unsigned (&pf)[96], const mg_task & t, int nsteps, wa_f16 * xin, int lane) {
+    if constexpr (!Q) return mg_dot8<NS>(pf, t.wrow, t.valid, nsteps, xin, lane & 7, true);
+    else return mq_hsum8(mq_chain<NS>(pf, t.wl, t.dl, t.valid, 0, nsteps, (const int *) mq_xq(xin) + (size_t) (lane & 7) * nsteps, mq_xd(xin), 0.0f, true));
+}
+#define MG_RES16(Q) ((Q) ? 8 : 0)       /* lane (of 16) that holds the result of a 16-lane row */
+template <bool Q, int NS4>
+__device__ __forceinline__ mg_task mg_mk16(unsigned (&pf)[96], const wa_f16 * W, const float * D, const float * bias, int N, int K, int row0, int rows_wg,
+                                           int grp, int lane) {
+    if constexpr (!Q) { mg_task t = mg_task16<NS4>(pf, W, bias, N, K, row0, rows_wg, grp, lane); t.wl = nullptr; t.dl = nullptr; return t; }
+    else {
+        mg_task t;
+        const int ri = grp * 4 + (lane >> 4), nb = K >> 5, nbh = nb >> 1, half = (lane >> 3) & 1;
+        t.row = row0 + ri;
+        t.valid = ri < rows_wg && t.row < N;
+        t.wrow = nullptr;
+        t.wl = (const GAS int *) W + ((size_t) (t.valid ? t.row : 0) * 8 + (lane & 7)) * nb;
+        t.dl = (const GAS float *) D + (size_t) (t.valid ? t.row : 0) * nb;
+        t.bias = 0.0f; t.scale = 1.0f;
+        mq_pf<0>(pf, t.wl, t.dl, t.valid, half * nbh, (half + 1) * nbh);
+        if (t.valid && (lane & 15) == 8 && bias) t.bias = ((gcf) bias)[t.row];
+        return t;
+    }
+}
+template <bool Q, int NS4>
+__device__ __forceinline__ float mg_do16(unsigned (&pf)[96], const mg_task & t, int nsteps, wa_f16 * xin, int lane) {
+    if constexpr (!Q) return mg_dot16<NS4>(pf, t.wrow, t.valid, nsteps, xin, lane & 15, true);
+    else {
+        const int nbh = nsteps >> 1, half = (lane >> 3) & 1;
+        const int * xq_u = (const int *) mq_xq(xin) + (size_t) (lane & 7) * nsteps;
+        float acc = 0.0f;
+        if (half == 0) acc = mq_chain<0>(pf, t.wl, t.dl, t.valid, 0, nbh, xq_u, mq_xd(xin), 0.0f, true);
+        const float from_lower = dpp_f32<0x118>(acc);          // row_shr:8: lanes 8-15 take over the running sums of lanes 0-7
+        if (half == 1) acc = mq_chain<0>(pf, t.wl, t.dl, t.valid, nbh, nsteps, xq_u, mq_xd(xin), from_lower, true);
+        return mq_hsum8(acc);                                  // valid in lane 8 of the 16
+    }
 }
 
 // publish two F16 results (rows n, n+1 of lanes 16j and 16j+8) as one granule; returns the packed pair in lanes 16j
@@ -429,23 +563,26 @@ __device__ __forceinline__ void mg_pick(mg_kargs A, int lane, int * pk) {
 // -------------------------------------------------------------------------------------------------
 // final LayerNorm + logits = token_embedding . x (whisper.cpp:2820-2835): every workgroup, every wave
 // -------------------------------------------------------------------------------------------------
-template <int NS = 0>
+template <int NS = 0, bool Q = false>
 __device__ __forceinline__ void mg_prefetch_logits(mg_kargs A, unsigned (&pf)[96], bool & have_pf, int lane, int wave) {
     const int g = (int) blockIdx.x + (int) gridDim.x * wave;
     const int row = g * 8 + (lane >> 3);
     const bool valid = row < A->n_vocab;
-    mg_pf8<NS>(pf, (gch) A->te + (size_t) (valid ? row : 0) * A->d + 4 * (lane & 7), valid, A->d >> 5, 0);
+    if constexpr (Q) {
+        const int nb = A->d >> 5;
+        mq_pf<NS>(pf, (const GAS int *) A->te + ((size_t) (valid ? row : 0) * 8 + (lane & 7)) * nb, (const GAS float *) A->te_d + (size_t) (valid ? row : 0) * nb, valid, 0, nb);
+    } else mg_pf8<NS>(pf, (gch) A->te + (size_t) (valid ? row : 0) * A->d + 4 * (lane & 7), valid, A->d >> 5, 0);
     have_pf = true;
 }
-template <int NP3, int NS>
+template <int NP3, int NS, bool Q = false>
 __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char * smem, unsigned (&pf)[96], bool have_pf, const float (&gw)[NP3],
                                          const float (&gb)[NP3], int lane, int wave) {
     float  * xf  = (float *) smem;
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);
     double * lnred = (double *) (smem + MG_LNRED_OFF);
     const int d = A->d, nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab;
-    mg_ln3<NP3>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, mg_slot(wave, MG_EX_FINAL), lane, xf, xin, lnred, 3000u,
-                blockIdx.x == 0 && wave == 0 ? (A->n_layer * 8) * 8 : -1, ((const int *) (smem + MG_PICK_OFF))[0]);
+    mg_ln3<NP3, Q>(A, c, A->n_layer > 0 ? mg_edge(A, A->n_layer - 1, E_X3) : nullptr, gw, gb, mg_slot(wave, MG_EX_FINAL), lane, xf, xin, lnred, 3000u,
+                   blockIdx.x == 0 && wave == 0 ? (A->n_layer * 8) * 8 : -1, ((const int *) (smem + MG_PICK_OFF))[0]);
     const int NG = (n_vocab + 7) >> 3;
     GAS float * logits = (GAS float *) A->logits;
     // sampling state after this launch's token -> which logits the next pick may choose (whisper.cpp:6264-6302)
@@ -463,12 +600,19 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
     const int ns = d >> 5;
     auto grp  = [&](int j) { return wg + nwg * (wave + MG_NW * j); };
     auto wrow = [&](int j) { const int row = grp(j) * 8 + (lane >> 3); return (gch) A->te + (size_t) (row < n_vocab ? row : 0) * d + 4 * (lane & 7); };
+    auto qwl  = [&](int j) { const int row = grp(j) * 8 + (lane >> 3); return (const GAS int *) A->te + ((size_t) (row < n_vocab ? row : 0) * 8 + (lane & 7)) * ns; };
+    auto qdl  = [&](int j) { const int row = grp(j) * 8 + (lane >> 3); return (const GAS float *) A->te_d + (size_t) (row < n_vocab ? row : 0) * ns; };
     auto vld  = [&](int j) { return grp(j) * 8 + (lane >> 3) < n_vocab; };
+    auto load = [&](int j, unsigned (&buf)[96]) {
+        if constexpr (Q) mq_pf<NS>(buf, qwl(j), qdl(j), vld(j), 0, ns); else mg_pf8<NS>(buf, wrow(j), vld(j), ns, 0);
+    };
     auto one = [&](int j, unsigned (&buf)[96]) {
         const int row = grp(j) * 8 + (lane >> 3);
         const bool valid = row < n_vocab;
         const unsigned mw = valid && (lane & 7) == 0 ? smask[row >> 5] : 0xffffffffu;
-        const float r = mg_dot8<NS>(buf, wrow(j), valid, ns, xin, lane & 7, ns <= 48);
+        float r;
+        if constexpr (Q) r = mq_hsum8(mq_chain<NS>(buf, qwl(j), qdl(j), valid, 0, ns, (const int *) mq_xq(xin) + (size_t) (lane & 7) * ns, mq_xd(xin), 0.0f, ns <= MQ_PF));
+        else r = mg_dot8<NS>(buf, wrow(j), valid, ns, xin, lane & 7, ns <= 48);
         if (valid && (lane & 7) == 0) {
             logits[row] = r;
             if (!((mw >> (row & 31)) & 1u)) {
@@ -481,12 +625,12 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
             }
         }
     };
-    if (!have_pf && grp(0) < NG) mg_pf8<NS>(pf, wrow(0), vld(0), ns, 0);
+    if (!have_pf && grp(0) < NG) load(0, pf);
     for (int j = 0; grp(j) < NG; j += 2) {
-        if (grp(j + 1) < NG) mg_pf8<NS>(pf2, wrow(j + 1), vld(j + 1), ns, 0);
+        if (grp(j + 1) < NG) load(j + 1, pf2);
         one(j, pf);
         if (grp(j + 1) >= NG) break;
-        if (grp(j + 2) < NG) mg_pf8<NS>(pf, wrow(j + 2), vld(j + 2), ns, 0);
+        if (grp(j + 2) < NG) load(j + 2, pf);
         one(j + 1, pf2);
     }
     {   // this workgroup's record
@@ -520,7 +664,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
 // wave 3 the two out-projections, wave 4 the cross query, wave 5 FC2; waves 6,7 help gather the 4d-wide FC2 input.
 // Every wave loads the weights of its NEXT task right after finishing the current one.
 // -------------------------------------------------------------------------------------------------
-template <int NP3, int NS>
+template <int NP3, int NS, bool Q = false>
 __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
@@ -551,11 +695,11 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     mg_ln_params<NP3>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
     if (wave == 0) mg_pick(A, lane, pk);
     mg_task t; t.valid = false; t.row = 0; t.wrow = nullptr; t.bias = 0.f; t.scale = 1.f;
-    if (wave == 1 || wave == 2) t = mg_task8<NS>(pf, Ly[0].qkv_w, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
-    else if (wave == 3)         t = mg_task8<NS>(pf, Ly[0].out_w, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
-    else if (wave == 4)         t = mg_task8<NS>(pf, Ly[0].cq_w, Ly[0].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
-    else if (wave == 5)         t = mg_task16<4 * NS>(pf, Ly[0].fc2_w, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
-    else if (wave >= 6)         mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);      // held until the final phase
+    if (wave == 1 || wave == 2) t = mg_mk8<Q, NS>(pf, Ly[0].qkv_w, Ly[0].qkv_d, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+    else if (wave == 3)         t = mg_mk8<Q, NS>(pf, Ly[0].out_w, Ly[0].out_d, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+    else if (wave == 4)         t = mg_mk8<Q, NS>(pf, Ly[0].cq_w, Ly[0].cq_d, Ly[0].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+    else if (wave == 5)         t = mg_mk16<Q, 4 * NS>(pf, Ly[0].fc2_w, Ly[0].fc2_d, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
+    else if (wave >= 6)         mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);      // held until the final phase
     mg_barrier();                   // the picked token is in LDS for the three embedding waves
     if (wave >= 3 && wave <= 5) {   // GELU table -> LDS by LDS-DMA (no registers, nothing waits here); first needed by FC1 of layer 0
         const GAS u32x4 * src = (const GAS u32x4 *) A->gelu;
@@ -566,9 +710,9 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         // ---------------- P1: LayerNorm + q|k|v ----------------
-        mg_ln3<NP3>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
+        mg_ln3<NP3, Q>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
         mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, mg_slot(wave, MG_EX_P4), lane);
-        if (MG_DEFER && l > 0 && wave == 5) t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, 0, lane);      // deferred from the previous layer's P8
+        if (MG_DEFER && l > 0 && wave == 5) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, 0, lane);      // deferred from the previous layer's P8
         // (Wide models give a workgroup more row groups than the one per wave that is prefetched.  The waves idle in a phase then
         //  assist: they take the extra groups on demand - overwriting the rows they hold for a later phase - and fetch those again
         //  afterwards, long before that phase.  ggml-small and below: one group per wave, nothing changes.)
@@ -577,8 +721,8 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             bool assisted = false;
             gu64 * eq = mg_edge(A, l, E_QKV);
             for (int grp = wave - 1; grp < g_qkv; grp += BIG ? 4 : 2) {
-                if (grp >= 2) { t = mg_task8<NS>(pf, Y.qkv_w, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane); assisted = true; }
-                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 2) { t = mg_mk8<Q, NS>(pf, Y.qkv_w, Y.qkv_d, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane); assisted = true; }
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
                 v = v + t.bias;
                 v = v * t.scale;
                 const unsigned pk = mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
@@ -589,88 +733,90 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 }
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 0) * 8 + 3, mg_now());
-            if (own && !MG_DEFER) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
-            else if (assisted) t = wave == 3 ? mg_task8<NS>(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, 0, lane)
-                                             : mg_task8<NS>(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+            if (own && !MG_DEFER) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+            else if (assisted) t = wave == 3 ? mg_mk8<Q, NS>(pf, Y.out_w, Y.out_d, Y.out_b, nullptr, d, d, row_d, r_d, 0, lane)
+                                             : mg_mk8<Q, NS>(pf, Y.cq_w, Y.cq_d, Y.cq_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P3: self-attention out-projection + residual ----------------
         {
-            const int qs = mg_slot(wave, MG_EX_AO), sg = mg_seg(d >> 1), j0 = qs * sg, j1 = min(d >> 1, j0 + sg);
-            if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
+            const int qs = mg_slot(wave, MG_EX_AO), sg = mg_seg(Q ? d : d >> 1), j0 = qs * sg, j1 = min(Q ? d : d >> 1, j0 + sg);
+            if constexpr (Q) { if (qs >= 0) mg_gather_q8<NP3>(c, mg_edge(A, l, E_AO), j0, j1, lane, xin, d >> 5, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1); }
+            else if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
         }
         mg_barrier();
         // (MG_DEFER: a wave's next weights are requested only once the CU's NEXT gather is over - a poll queued behind 24-48 KB of
         //  weight loads waits for them: hand-off-1to1 costs 0.8 us with quiet endpoints, 2.3-3.5 behind 8-15 streaming waves.)
-        if (MG_DEFER && (wave == 1 || wave == 2)) t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+        if (MG_DEFER && (wave == 1 || wave == 2)) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
         if (wave == 3 || (BIG && wave == 5)) {        // wave 5 assists (it holds this layer's FC2 rows, next needed in P8)
             const bool own = !BIG || wave == 3;
             bool assisted = false;
             gu64 * ex = mg_edge(A, l, E_X1);
             for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
-                if (grp >= 1) { t = mg_task8<NS>(pf, Y.out_w, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
-                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 1) { t = mg_mk8<Q, NS>(pf, Y.out_w, Y.out_d, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 1) * 8 + 3, mg_now());
-            if (own && !MG_DEFER) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
-            else if (assisted) t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, 0, lane);
+            if (own && !MG_DEFER) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else if (assisted) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
-        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
-        if (MG_DEFER && wave == 3) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
+        if (MG_DEFER && wave == 3) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, mg_slot(wave, MG_EX_P7), lane);
         if (wave == 4 || (BIG && wave == 3)) {        // wave 3 assists (it holds this layer's cross-attention output rows, next needed in P6)
             const bool own = !BIG || wave == 4;
             bool assisted = false;
             gu64 * eq = mg_edge(A, l, E_QC);
             for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
-                if (grp >= 1) { t = mg_task8<NS>(pf, Y.cq_w, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
-                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 1) { t = mg_mk8<Q, NS>(pf, Y.cq_w, Y.cq_d, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
                 v = v + t.bias;
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
             if (own && !MG_DEFER) {
-                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
-                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
-            } else if (assisted) t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+                if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+            } else if (assisted) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P6: cross-attention out-projection + residual ----------------
         {
-            const int qs = mg_slot(wave, MG_EX_AO2), sg = mg_seg(d >> 1), j0 = qs * sg, j1 = min(d >> 1, j0 + sg);
-            if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
+            const int qs = mg_slot(wave, MG_EX_AO2), sg = mg_seg(Q ? d : d >> 1), j0 = qs * sg, j1 = min(Q ? d : d >> 1, j0 + sg);
+            if constexpr (Q) { if (qs >= 0) mg_gather_q8<NP3>(c, mg_edge(A, l, E_AO2), j0, j1, lane, xin, d >> 5, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1); }
+            else if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
         }
         mg_barrier();
         if (MG_DEFER && wave == 4) {
-            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
-            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
         }
         if (wave == 3 || (BIG && wave == 4)) {        // wave 4 assists (it holds the next layer's cross-query rows)
             const bool own = !BIG || wave == 3;
             bool assisted = false;
             gu64 * ex = mg_edge(A, l, E_X2);
             for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
-                if (grp >= 1) { t = mg_task8<NS>(pf, Y.co_w, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
-                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 1) { t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
             if (own && !MG_DEFER) {
-                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
-                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+                if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
-                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
-                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+                if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
             }
         }
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
         if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
-        mg_ln3<NP3>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
+        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
         if (MG_DEFER && wave == 3) {
-            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
-            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+            else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
         }
         if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
         else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, mg_slot(wave, MG_EX_FINAL), lane);
@@ -679,56 +825,58 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             bool assisted = false;
             gu64 * eh = mg_edge(A, l, E_HF);
             for (int grp = wave - 1; grp < g_ff; grp += BIG ? 4 : 2) {
-                if (grp >= 2) { t = mg_task8<NS>(pf, Y.fc1_w, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane); assisted = true; }
-                float v = mg_dot8<NS>(pf, t.wrow, t.valid, d >> 5, xin, lane & 7, true);
+                if (grp >= 2) { t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane); assisted = true; }
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
                 v = v + t.bias;
                 float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
                 if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
-                mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
+                if constexpr (Q) { if (t.valid && (lane & 7) == 0) gr_store(eh + t.row, seq, __float_as_uint(gl)); }      // F32: the second MLP product quantises from it
+                else mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
             if (own && !MG_DEFER) {
-                if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
-                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+                if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_d, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+                else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
-                if (l + 1 >= L) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
-                else t = wave == 3 ? mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane)
-                                   : mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+                if (l + 1 >= L) mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+                else t = wave == 3 ? mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane)
+                                   : mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
             }
         }
         // ---------------- P8: FC2 + residual ----------------
         {   // the widest hand-off (2d granules)
-            const int qs = mg_slot(wave, MG_EX_HF), sg = mg_seg(2 * d), i0 = qs * sg, i1 = min(2 * d, i0 + sg);
-            if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
+            const int qs = mg_slot(wave, MG_EX_HF), sg = mg_seg(Q ? d4 : 2 * d), i0 = qs * sg, i1 = min(Q ? d4 : 2 * d, i0 + sg);
+            if constexpr (Q) { if (qs >= 0) mg_gather_q8<(NP3 == MG_NP3 ? 14 : 8)>(c, mg_edge(A, l, E_HF), i0, i1, lane, xin, d4 >> 5, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1); }
+            else if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
         mg_barrier();
         if (MG_DEFER && (wave == 1 || wave == 2)) {
-            if (l + 1 < L) t = mg_task8<NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
-            else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+            if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_d, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
+            else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
         }
         if (wave == 5 || (BIG && (wave == 3 || wave == 4))) {        // waves 3, 4 assist (as in P7)
             const bool own = !BIG || wave == 5;
             bool assisted = false;
             gu64 * ex = mg_edge(A, l, E_X3);
             for (int grp = own ? 0 : wave - 2; grp < g_d16; grp += BIG ? 3 : 1) {
-                if (grp >= 1) { t = mg_task16<4 * NS>(pf, Y.fc2_w, Y.fc2_b, d, d4, row_d, r_d, grp, lane); assisted = true; }
-                float v = mg_dot16<4 * NS>(pf, t.wrow, t.valid, d4 >> 5, xin, lane & 15, true);
+                if (grp >= 1) { t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, grp, lane); assisted = true; }
+                float v = mg_do16<Q, 4 * NS>(pf, t, d4 >> 5, xin, lane);
                 v = v + t.bias;
-                if (t.valid && (lane & 15) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
+                if (t.valid && (lane & 15) == MG_RES16(Q)) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 5) * 8 + 3, mg_now());
             if (own && (!MG_DEFER || l + 1 >= L)) {
-                if (l + 1 < L) t = mg_task16<4 * NS>(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
-                else mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
+                if (l + 1 < L) t = mg_mk16<Q, 4 * NS>(pf, Ly[l + 1].fc2_w, Ly[l + 1].fc2_d, Ly[l + 1].fc2_b, d, d4, row_d, r_d, 0, lane);
+                else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
-                if (l + 1 >= L) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
-                else t = wave == 3 ? mg_task8<NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane)
-                                   : mg_task8<NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+                if (l + 1 >= L) mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+                else t = wave == 3 ? mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane)
+                                   : mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
             }
         }
     }
-    if (L == 0 && wave >= 1 && wave <= 5) mg_prefetch_logits<NS>(A, pf, have_pf, lane, wave);
-    mg_final<NP3, NS>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
+    if (L == 0 && wave >= 1 && wave <= 5) mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+    mg_final<NP3, NS, Q>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -809,6 +957,7 @@ __device__ __forceinline__ float mg_score(const u32x4 & ka, const u32x4 & kb, co
 }
 
 // final tree over the 32 partial-sum chains + F64 leftovers, by threads 0..63 (tid = d_head index); then publish
+template <bool Q = false>                 // Q: the result leaves in F32, one granule per element (the out-projection quantises it from F32)
 __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 * vleft /* [nl][64] */, const wa_f16 * p16, int np, int nl,
                                                gu64 * edge, int h, unsigned seq, int tid) {
     if (tid < 64) {
@@ -824,9 +973,12 @@ __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 
         }
 #pragma unroll
         for (int cc = 0; cc < 32; ++cc) if (cc < nl) sumf += (double) prod[cc];
+        if constexpr (Q) gr_store(edge + h * 64 + tid, seq, __float_as_uint((float) sumf));
+        else {
         const unsigned hv = (unsigned) f2h((float) sumf);
         const unsigned hi = dpp_u32<0x101>(hv);          // row_shl:1: lane i reads lane i+1
         if ((tid & 1) == 0) gr_store(edge + ((h * 64 + tid) >> 1), seq, (hv & 0xffffu) | (hi << 16));
+        }
     }
 }
 
@@ -834,6 +986,7 @@ __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 
 // role: self-attention of head h (whisper.cpp:2636-2651), every layer.  The K/V cells of earlier tokens are copied
 // into LDS while the GEMV workgroups are busy with the previous phases; the new cell arrives with the query.
 // -------------------------------------------------------------------------------------------------
+template <bool Q = false>
 __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
@@ -937,16 +1090,16 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
             for (int i = 0; i < 4; ++i) M.part[(r0 + i) * 64 + lane] = acc[i];
         }
         mg_barrier();
-        mg_attn_finish(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid);
+        mg_attn_finish<Q>(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid);
         mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 3, mg_now());
         mg_barrier();
     }
     unsigned pf[96];
     bool have_pf = false;
     float gw[MG_NP3], gb[MG_NP3];
-    if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
+    if (wave >= 1) mg_prefetch_logits<0, Q>(A, pf, have_pf, lane, wave);
     mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, mg_slot(wave, MG_EX_FINAL), lane);
-    mg_final<MG_NP3, 0>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
+    mg_final<MG_NP3, 0, Q>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -969,6 +1122,7 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
 #define MG_CGR_XCC 16                                   // (layer 0 area only) the four workgroups' XCC_IDs
 #define MG_CGR_PART 64                                  // + (w - 1) * 576: 512 chain sums + 8 leftover probabilities
 
+template <bool Q = false>
 __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
@@ -1135,7 +1289,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             }
             mg_barrier();
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 7, mg_now());
-            mg_attn_finish(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid);
+            mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid);
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 3, mg_now());
         }
         mg_barrier();
@@ -1143,9 +1297,9 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
     unsigned pf[96];
     bool have_pf = false;
     float gw[MG_NP3], gb[MG_NP3];
-    if (wave >= 1) mg_prefetch_logits(A, pf, have_pf, lane, wave);
+    if (wave >= 1) mg_prefetch_logits<0, Q>(A, pf, have_pf, lane, wave);
     mg_ln_params<MG_NP3>(gw, gb, A->lnf_w, A->lnf_b, A->d, mg_slot(wave, MG_EX_FINAL), lane);
-    mg_final<MG_NP3, 0>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
+    mg_final<MG_NP3, 0, Q>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
 }
 
 __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A) {
@@ -1155,6 +1309,16 @@ __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A
     if (role == 0) { if (A.d == 768) mg_role_gemv<2, 24>(Ap, idx); else if (A.d < 768) mg_role_gemv<2, 0>(Ap, idx); else mg_role_gemv<MG_NP3, 0>(Ap, idx); }
     else if (role == 1) mg_role_self(Ap, idx);
     else                mg_role_cross(Ap, idx);
+}
+
+// the same step for a quantised model (Q5_0 / Q8_0 files): a kernel of its own, so that the F16 kernel's code and registers stay as tuned
+__global__ __launch_bounds__(MG_THREADS) void k_decode_mega_q(const wa_mega_args A) {
+    int role, idx;
+    mg_role_of((int) gridDim.x, A.n_head, (int) blockIdx.x, role, idx);
+    const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();
+    if (role == 0) { if (A.d == 768) mg_role_gemv<2, 24, true>(Ap, idx); else if (A.d < 768) mg_role_gemv<2, 0, true>(Ap, idx); else mg_role_gemv<MG_NP3, 0, true>(Ap, idx); }
+    else if (role == 1) mg_role_self<true>(Ap, idx);
+    else                mg_role_cross<true>(Ap, idx);
 }
 
 size_t wa_mega_lds_bytes() {
@@ -1172,7 +1336,9 @@ void wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg) {
     const size_t lds = wa_mega_lds_bytes();
     if (!attr_set) {
         (void) hipFuncSetAttribute((const void *) k_decode_mega, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) k_decode_mega_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_decode_mega, dim3(n_wg), dim3(MG_THREADS), lds, s, a);
+    if (a.quant) hipLaunchKernelGGL(k_decode_mega_q, dim3(n_wg), dim3(MG_THREADS), lds, s, a);
+    else         hipLaunchKernelGGL(k_decode_mega, dim3(n_wg), dim3(MG_THREADS), lds, s, a);
 }
