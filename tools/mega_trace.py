@@ -8,7 +8,8 @@ os.environ["WHISPER_AMD_MEGA_DBG"] = "1"
 name = sys.argv[1] if len(sys.argv) > 1 else "small"
 n_past = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
-ctx = W.WhisperContext.new_with_params(wsynth.model_path(name), W.WhisperContextParameters(lib), lib=lib)
+mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)      # "small:q5_0" = the quantised file
+ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib), lib=lib)
 st = ctx.create_state()
 st.pcm_to_mel(wsynth.synth_audio(480000, 0)); st.encode(0)
 L, d, nv, H = ctx.model_n_text_layer(), ctx.model_n_text_state(), ctx.n_vocab(), ctx.model_n_text_head()
@@ -25,7 +26,7 @@ order = [0, 6, 1, 2, 7, 3, 4, 5]
 for l in range(L):
     for p in order:
         r = tr[l * 8 + p]
-        extra = "  scores %.2f softmax %.2f pv %.2f gathered %.2f" % (us(r[4]), us(r[5]), us(r[6]), us(r[7])) if p >= 6 else ("  ln: sums %.2f squares %.2f" % (us(r[4]), us(r[5])) if p in (0, 2, 4) else "")
+        extra = "  scores %.2f softmax %.2f pv %.2f gathered %.2f" % (us(r[4]), us(r[5]), us(r[6]), us(r[7])) if p >= 6 else ("  ln: sums %.2f squares %.2f" % (us(r[4]), us(r[5])) if p in (0, 2, 4) else ("  gathered+barrier %.2f dot %.2f" % (us(r[4]), us(r[5])) if p == 5 else ""))
         print("L%02d %-10s in %8.2f (%4d polls)  ready %8.2f  pub %8.2f%s" % (l, names[p], us(r[0]), r[1], us(r[2]) if r[2] else 0.0, us(r[3]), extra))
 r = tr[L * 8]
 print("final      in %8.2f (%4d polls)  ready %8.2f  done %8.2f" % (us(r[0]), r[1], us(r[2]), us(r[3])))

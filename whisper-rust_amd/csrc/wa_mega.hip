@@ -850,6 +850,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             else if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
         mg_barrier();
+        mg_trace(A, wg == 0 && wave == 5 && lane == 0, (l * 8 + 5) * 8 + 4, mg_now());
         if (MG_DEFER && (wave == 1 || wave == 2)) {
             if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_d, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
             else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
