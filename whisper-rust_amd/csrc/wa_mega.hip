@@ -61,6 +61,24 @@ __device__ __forceinline__ void gr_store_l(gu64 * g, unsigned seq, unsigned v, b
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xf, 0xf, true); }
+// The lane index behind an opaque move: addresses and masks derived from it are recomputed where they are used instead of being hoisted
+// out of the layer loop - where they sat in scratch and came back behind an s_waitcnt vmcnt(0), i.e. behind the wave's weight prefetch.
+__device__ __forceinline__ int mq_fresh(int) {
+    unsigned z = 0; asm volatile("" : "+v"(z));         // an opaque zero: the two mbcnt below cannot be merged with an earlier pair (nor kept, nor spilled)
+    return (int) __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
+// quantize_row_q8_0 (arch/x86/quants.c) of whole 32-element blocks held one value per lane (as wa_q8_store), the quads packed over DPP:
+// one LDS word per four lanes at q32 (the lane's quad row and block), the scale rounded through F16 at dsc.  All lanes take part.
+__device__ __forceinline__ void mq_put(float y, bool act, unsigned * q32, float * dsc, int lane) {
+    float a = fabsf(y);
+    a = fmaxf(a, dpp_f32<0x128>(a)); a = fmaxf(a, dpp_f32<0x124>(a)); a = fmaxf(a, dpp_f32<0x122>(a)); a = fmaxf(a, dpp_f32<0x121>(a));
+    a = fmaxf(a, __shfl_xor(a, 16, 32));
+    const float dq = a / 127.f, id = a != 0.0f ? 127.f / a : 0.0f;
+    const unsigned q = (unsigned) (int) rintf(y * id) & 0xffu;
+    const unsigned w = q | (dpp_u32<0x101>(q) << 8) | (dpp_u32<0x102>(q) << 16) | (dpp_u32<0x103>(q) << 24);      // row_shl:1..3
+    if (act && (lane & 3) == 0) *q32 = w;
+    if (act && (lane & 31) == 0) *dsc = h2f(f2h(dq));
+}
 
 __device__ __forceinline__ gu64 * mg_edge(mg_kargs A, int layer, int e) {
     return (gu64 *) A->granules + ((size_t) layer * WA_MEGA_EDGES + e) * A->edge_stride;
@@ -72,7 +90,10 @@ __device__ __forceinline__ void mg_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 // (quantised models) LDS of the quantised activation row inside the xin area: quants [4d] bytes, then the block scales
 __device__ __forceinline__ int8_t * mq_xq(wa_f16 * xin) { return (int8_t *) xin; }
-__device__ __forceinline__ float  * mq_xd(wa_f16 * xin) { return (float *) ((unsigned char *) xin + 4 * WA_MEGA_MAX_D); }
+__device__ __forceinline__ float  * mq_xd(wa_f16 * xin) { return (float *) ((unsigned char *) xin + 6 * WA_MEGA_MAX_D); }
+// words between the quad rows u = 0..7 of the activation row: nb | 8 puts the eight 16-byte reads of a product step on disjoint banks
+// (u * nb alone: nb = 96 folds them onto two)
+__device__ __forceinline__ int mq_ld(int nb) { return nb | 8; }
 
 // optional timeline (tools/mega_debug.py): 100 MHz wall-clock ticks of one workgroup per role, behind the cross-attention dumps
 __device__ __forceinline__ void mg_trace(mg_kargs A, bool who, int slot, unsigned v) {
@@ -120,6 +141,7 @@ __device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int la
 #define MG_EX_AO 0x06u      /* waves 1, 2: FC1 rows */
 #define MG_EX_AO2 0x10u     /* wave 4: next cross-query rows */
 #define MG_EX_HF 0x06u      /* waves 1, 2: next QKV rows */
+#define MG_EX_HFQ 0x18u     /* quantised, whole-block FC1: waves 3, 4 have just asked for the next out-projection / cross-query rows */
 #define MG_EX_FINAL 0x20u   /* wave 5: first logits rows */
 __device__ __forceinline__ int mg_slot(int wave, unsigned ex) {
     if ((ex >> wave) & 1u) return -1;
@@ -182,7 +204,9 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
     const double a = ((lnred[6] + lnred[7]) + (lnred[8] + lnred[9])) + (lnred[10] + lnred[11]);
     float mean_hi;
     bool need_seq = false;
-    if (!wa_sum_bounds(s, a, d, mean, mean_hi, A->rn_d)) {       // rare (a mean near zero): second-level certificate over all elements
+    int dd = d;
+    if constexpr (Q) asm volatile("" : "+s"(dd));      // (the certificate's F64 constants of d are recomputed here rather than kept over the layer loop in scratch)
+    if (!wa_sum_bounds(s, a, dd, mean, mean_hi, A->rn_d)) {       // rare (a mean near zero): second-level certificate over all elements
         if (q >= 0) {
             bool same = true;
 #pragma unroll
@@ -216,17 +240,19 @@ __device__ __forceinline__ void mg_ln3(mg_kargs A, mg_ctl & c, gu64 * edge /* nu
             variance = (float) (s2 / (double) d);
         }
         const float scale = 1.0f / sqrtf(variance + A->eps);
+        // (Q: a slot's part is whole 32-element blocks - i0, d % 32 == 0 -; lane's block at k is (i0 >> 5) + (lane >> 5) + 2 k)
+        const int ln = mq_fresh(lane);
+        unsigned * q32 = (unsigned *) mq_xq(xin) + ((ln & 31) >> 2) * mq_ld(d >> 5) + (i0 >> 5) + (ln >> 5);
+        float * dsc = mq_xd(xin) + (i0 >> 5) + (ln >> 5);
 #pragma unroll
         for (int k = 0; k < NP3; ++k) {
-            const int i = i0 + lane + 64 * k;
-            if (i < i1) {
-                float y = xv[k] - mean;
-                y = y * scale;
-                y = y * gw[k];
-                y = y + gb[k];
-                if constexpr (Q) wa_q8_store(y, 0, i >> 5, i & 31, d >> 5, mq_xq(xin), mq_xd(xin));      // (a slot's part is whole 32-element blocks: i0, d % 32 == 0)
-                else xin[i] = f2h(y);
-            }
+            const int i = i0 + ln + 64 * k;
+            float y = xv[k] - mean;
+            y = y * scale;
+            y = y * gw[k];
+            y = y + gb[k];
+            if constexpr (Q) mq_put(y, i < i1, q32 + 2 * k, dsc + 2 * k, ln);
+            else if (i < i1) xin[i] = f2h(y);
         }
         if (tslot >= 0) mg_trace(A, lane == 0, tslot + 2, mg_now());
     }
@@ -251,8 +277,25 @@ __device__ __forceinline__ void mg_gather_q8(mg_ctl & c, gu64 * edge, int i0, in
     unsigned v[NPL];
     const unsigned sp = mg_sweep<NPL>(edge, [&](int k) { const int i = i0 + lane + 64 * k; return i < i1 ? i : -1; }, c, lane, v, code);
     if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
+    const int ln = mq_fresh(lane);
+    unsigned * q32 = (unsigned *) mq_xq(xin) + ((ln & 31) >> 2) * mq_ld(nb) + (i0 >> 5) + (ln >> 5);
+    float * dsc = mq_xd(xin) + (i0 >> 5) + (ln >> 5);
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) { const int i = i0 + lane + 64 * k; if (i < i1) wa_q8_store(__uint_as_float(v[k]), 0, i >> 5, i & 31, nb, mq_xq(xin), mq_xd(xin)); }
+    for (int k = 0; k < NPL; ++k) mq_put(__uint_as_float(v[k]), i0 + ln + 64 * k < i1, q32 + 2 * k, dsc + 2 * k, ln);
+}
+
+// wave(s): blocks that were quantised by their producer - 9 granules per block (quads 0..7, scale) - copied into the activation row in LDS
+template <int NPL>
+__device__ __forceinline__ void mg_gather_qb(mg_ctl & c, gu64 * edge, int i0, int i1, int lane, wa_f16 * xin, int nb, unsigned code, mg_kargs A = nullptr,
+                                             int tslot = -1) {
+    unsigned v[NPL];
+    const unsigned sp = mg_sweep<NPL>(edge, [&](int k) { const int i = i0 + lane + 64 * k; return i < i1 ? i : -1; }, c, lane, v, code);
+    if (tslot >= 0) { mg_trace(A, lane == 0, tslot, mg_now()); mg_trace(A, lane == 0, tslot + 1, sp); }
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int i = i0 + lane + 64 * k;
+        if (i < i1) { const int b = i / 9, kq = i - 9 * b; if (kq < 8) ((unsigned *) mq_xq(xin))[kq * mq_ld(nb) + b] = v[k]; else mq_xd(xin)[b] = __uint_as_float(v[k]); }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -459,7 +502,7 @@ __device__ __forceinline__ mg_task mg_mk8(unsigned (&pf)[96], const wa_f16 * W, 
 template <bool Q, int NS>
 __device__ __forceinline__ float mg_do8(unsigned (&pf)[96], const mg_task & t, int nsteps, wa_f16 * xin, int lane) {
     if constexpr (!Q) return mg_dot8<NS>(pf, t.wrow, t.valid, nsteps, xin, lane & 7, true);
-    else return mq_hsum8(mq_chain<NS>(pf, t.wl, t.dl, t.valid, 0, nsteps, (const int *) mq_xq(xin) + (size_t) (lane & 7) * nsteps, mq_xd(xin), 0.0f, true));
+    else return mq_hsum8(mq_chain<NS>(pf, t.wl, t.dl, t.valid, 0, nsteps, (const int *) mq_xq(xin) + (lane & 7) * mq_ld(nsteps), mq_xd(xin), 0.0f, true));
 }
 #define MG_RES16(Q) ((Q) ? 8 : 0)       /* lane (of 16) that holds the result of a 16-lane row */
 template <bool Q, int NS4>
@@ -484,11 +527,42 @@ template <bool Q, int NS4>
 __device__ __forceinline__ float mg_do16(unsigned (&pf)[96], const mg_task & t, int nsteps, wa_f16 * xin, int lane) {
     if constexpr (!Q) return mg_dot16<NS4>(pf, t.wrow, t.valid, nsteps, xin, lane & 15, true);
     else {
-        const int nbh = nsteps >> 1, half = (lane >> 3) & 1;
-        const int * xq_u = (const int *) mq_xq(xin) + (size_t) (lane & 7) * nsteps;
+        const int nbh = NS4 > 0 ? NS4 / 2 : nsteps >> 1, half = (lane >> 3) & 1;      // (known at compile time for ggml-small: no guards, the LDS reads in one batch)
+        const int * xq_u = (const int *) mq_xq(xin) + (lane & 7) * mq_ld(nsteps);
         float acc = 0.0f;
+        if (nbh <= MQ_PF) {
+            // Everything but the chain itself for BOTH halves at once, in place (pf[j] = (float) dot4, pf[48 + j] = dw dx); what is left
+            // in series is one fma per block: the lower half's chain, then the upper half's from its result.
+#pragma unroll
+            for (int c = 0; c < MQ_PF / 4; ++c) {
+                if (4 * c < nbh) {
+                    const mq_i4 x = *(const mq_i4 *) (xq_u + half * nbh + 4 * c);
+                    const mq_f4 dx = *(const mq_f4 *) (mq_xd(xin) + half * nbh + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pf[4 * c + e] = __float_as_uint((float) __builtin_amdgcn_sdot4((int) pf[4 * c + e], x[e], 0, false));
+                        pf[MQ_PF + 4 * c + e] = __float_as_uint(__uint_as_float(pf[MQ_PF + 4 * c + e]) * dx[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < MQ_PF / 4; ++c)
+                if (4 * c < nbh) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = fmaf(__uint_as_float(pf[MQ_PF + 4 * c + e]), __uint_as_float(pf[4 * c + e]), acc);
+                }
+            const float from_lower = dpp_f32<0x118>(acc);      // row_shr:8: lanes 8-15 take over the running sums of lanes 0-7
+            acc = from_lower;                                  // (the lower half runs the second chain too; its result is not used)
+#pragma unroll
+            for (int c = 0; c < MQ_PF / 4; ++c)
+                if (4 * c < nbh) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = fmaf(__uint_as_float(pf[MQ_PF + 4 * c + e]), __uint_as_float(pf[4 * c + e]), acc);
+                }
+            return mq_hsum8(acc);                              // valid in lane 8 of the 16
+        }
         if (half == 0) acc = mq_chain<0>(pf, t.wl, t.dl, t.valid, 0, nbh, xq_u, mq_xd(xin), 0.0f, true);
-        const float from_lower = dpp_f32<0x118>(acc);          // row_shr:8: lanes 8-15 take over the running sums of lanes 0-7
+        const float from_lower = dpp_f32<0x118>(acc);
         if (half == 1) acc = mq_chain<0>(pf, t.wl, t.dl, t.valid, nbh, nsteps, xq_u, mq_xd(xin), from_lower, true);
         return mq_hsum8(acc);                                  // valid in lane 8 of the 16
     }
@@ -611,7 +685,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
         const bool valid = row < n_vocab;
         const unsigned mw = valid && (lane & 7) == 0 ? smask[row >> 5] : 0xffffffffu;
         float r;
-        if constexpr (Q) r = mq_hsum8(mq_chain<NS>(buf, qwl(j), qdl(j), valid, 0, ns, (const int *) mq_xq(xin) + (size_t) (lane & 7) * ns, mq_xd(xin), 0.0f, ns <= MQ_PF));
+        if constexpr (Q) r = mq_hsum8(mq_chain<NS>(buf, qwl(j), qdl(j), valid, 0, ns, (const int *) mq_xq(xin) + (lane & 7) * mq_ld(ns), mq_xd(xin), 0.0f, ns <= MQ_PF));
         else r = mg_dot8<NS>(buf, wrow(j), valid, ns, xin, lane & 7, ns <= 48);
         if (valid && (lane & 7) == 0) {
             logits[row] = r;
@@ -668,13 +742,20 @@ template <int NP3, int NS, bool Q = false>
 __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+#define MG_FRESH() do { if constexpr (Q) lane = mq_fresh(lane); } while (0)      /* see mq_fresh: nothing lane-derived lives across phases */
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = __builtin_amdgcn_readfirstlane(idx_), nG = (int) gridDim.x - 5 * A->n_head;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
     unsigned pf[96];
     bool have_pf = false;
     constexpr bool BIG = NS == 0 && NP3 == MG_NP3;       // d > 768: more row groups per workgroup than prefetching waves - the idle waves assist
+    // Quantised, d <= 768: the first MLP product is owned by WHOLE Q8_0 blocks - workgroup b < 4d / 32 has rows 32 b .. 32 b + 31, eight per
+    // wave 1..4 -, so that the block leaves already quantised (8 quads + scale: 9 granules instead of 32 F32 values, and no consumer
+    // quantises it again).  The four waves meet over an LDS counter; the last one to arrive quantises and publishes.
+    constexpr bool QB = Q && !BIG && MG_DEFER;
+    float    * fc1x   = (float *) (smem + WA_MEGA_MAX_D * 4 + 7 * WA_MEGA_MAX_D);           // [32] the block's GELU outputs (behind xq / xd in the xin area)
+    unsigned * fc1cnt = (unsigned *) (smem + WA_MEGA_MAX_D * 4 + 7 * WA_MEGA_MAX_D + 128);  // arrivals, never reset: a multiple of 4 after every layer
 
     float  * xf  = (float *) smem;                               // [d]   residual row (F32)
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);        // [4d]  GEMV input (F16)
@@ -694,6 +775,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     int * pk = (int *) (smem + MG_PICK_OFF);
     mg_ln_params<NP3>(gw, gb, Ly[0].ln1_w, Ly[0].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
     if (wave == 0) mg_pick(A, lane, pk);
+    if (QB && wave == 0 && lane == 0) *fc1cnt = 0u;
     mg_task t; t.valid = false; t.row = 0; t.wrow = nullptr; t.bias = 0.f; t.scale = 1.f;
     if (wave == 1 || wave == 2) t = mg_mk8<Q, NS>(pf, Ly[0].qkv_w, Ly[0].qkv_d, Ly[0].qkv_b, Ly[0].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
     else if (wave == 3)         t = mg_mk8<Q, NS>(pf, Ly[0].out_w, Ly[0].out_d, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -710,7 +792,9 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         // ---------------- P1: LayerNorm + q|k|v ----------------
+        MG_FRESH();
         mg_ln3<NP3, Q>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
+        MG_FRESH();
         mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, mg_slot(wave, MG_EX_P4), lane);
         if (MG_DEFER && l > 0 && wave == 5) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, 0, lane);      // deferred from the previous layer's P8
         // (Wide models give a workgroup more row groups than the one per wave that is prefetched.  The waves idle in a phase then
@@ -738,15 +822,17 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                                              : mg_mk8<Q, NS>(pf, Y.cq_w, Y.cq_d, Y.cq_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P3: self-attention out-projection + residual ----------------
+        MG_FRESH();
         {
-            const int qs = mg_slot(wave, MG_EX_AO), sg = mg_seg(Q ? d : d >> 1), j0 = qs * sg, j1 = min(Q ? d : d >> 1, j0 + sg);
-            if constexpr (Q) { if (qs >= 0) mg_gather_q8<NP3>(c, mg_edge(A, l, E_AO), j0, j1, lane, xin, d >> 5, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1); }
+            const int qs = mg_slot(wave, MG_EX_AO), sg = mg_seg(Q ? 9 * (d >> 5) : d >> 1), j0 = qs * sg, j1 = min(Q ? 9 * (d >> 5) : d >> 1, j0 + sg);
+            if constexpr (Q) { if (qs >= 0) mg_gather_qb<1>(c, mg_edge(A, l, E_AO), j0, j1, lane, xin, d >> 5, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1); }
             else if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO), j0, j1, lane, (unsigned *) xin, 200u + l, A, wg == 0 && wave == 0 ? (l * 8 + 1) * 8 : -1);
         }
         mg_barrier();
+        MG_FRESH();
         // (MG_DEFER: a wave's next weights are requested only once the CU's NEXT gather is over - a poll queued behind 24-48 KB of
         //  weight loads waits for them: hand-off-1to1 costs 0.8 us with quiet endpoints, 2.3-3.5 behind 8-15 streaming waves.)
-        if (MG_DEFER && (wave == 1 || wave == 2)) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+        if (MG_DEFER && (wave == 1 || wave == 2)) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, QB ? 32 * wg : row_ff, QB ? 32 : r_ff, wave - 1, lane);
         if (wave == 3 || (BIG && wave == 5)) {        // wave 5 assists (it holds this layer's FC2 rows, next needed in P8)
             const bool own = !BIG || wave == 3;
             bool assisted = false;
@@ -762,7 +848,9 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             else if (assisted) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
+        MG_FRESH();
         mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
+        MG_FRESH();
         if (MG_DEFER && wave == 3) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, mg_slot(wave, MG_EX_P7), lane);
         if (wave == 4 || (BIG && wave == 3)) {        // wave 3 assists (it holds this layer's cross-attention output rows, next needed in P6)
@@ -776,19 +864,22 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
-            if (own && !MG_DEFER) {
+            if (QB) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, 32 * wg, 32, 3, lane);      // its eight rows of the block; next needed in P7
+            else if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
                 else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
             } else if (assisted) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         }
         // ---------------- P6: cross-attention out-projection + residual ----------------
+        MG_FRESH();
         {
-            const int qs = mg_slot(wave, MG_EX_AO2), sg = mg_seg(Q ? d : d >> 1), j0 = qs * sg, j1 = min(Q ? d : d >> 1, j0 + sg);
-            if constexpr (Q) { if (qs >= 0) mg_gather_q8<NP3>(c, mg_edge(A, l, E_AO2), j0, j1, lane, xin, d >> 5, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1); }
+            const int qs = mg_slot(wave, MG_EX_AO2), sg = mg_seg(Q ? 9 * (d >> 5) : d >> 1), j0 = qs * sg, j1 = min(Q ? 9 * (d >> 5) : d >> 1, j0 + sg);
+            if constexpr (Q) { if (qs >= 0) mg_gather_qb<1>(c, mg_edge(A, l, E_AO2), j0, j1, lane, xin, d >> 5, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1); }
             else if (qs >= 0) mg_gather_h2<2>(c, mg_edge(A, l, E_AO2), j0, j1, lane, (unsigned *) xin, 400u + l, A, wg == 0 && wave == 0 ? (l * 8 + 3) * 8 : -1);
         }
         mg_barrier();
-        if (MG_DEFER && wave == 4) {
+        MG_FRESH();
+        if (MG_DEFER && !QB && wave == 4) {
             if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
             else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
         }
@@ -803,7 +894,8 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
-            if (own && !MG_DEFER) {
+            if (QB) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, 32 * wg, 32, 2, lane);
+            else if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
                 else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
@@ -812,14 +904,50 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             }
         }
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
+        MG_FRESH();
         if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
         mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
-        if (MG_DEFER && wave == 3) {
+        MG_FRESH();
+        if (MG_DEFER && !QB && wave == 3) {
             if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
             else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
         }
         if (l + 1 < L) mg_ln_params<NP3>(gw, gb, Ly[l + 1].ln1_w, Ly[l + 1].ln1_b, d, mg_slot(wave, MG_EX_P1), lane);
         else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, mg_slot(wave, MG_EX_FINAL), lane);
+        if (QB) {
+            if (wave >= 1 && wave <= 4) {
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
+                v = v + t.bias;
+                float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
+                if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
+                if ((lane & 7) == 0) fc1x[8 * (wave - 1) + (lane >> 3)] = gl;
+                unsigned arrived = 0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (LDS operations of a wave execute in order: the values are in place before the count moves)
+                if (lane == 0) arrived = __hip_atomic_fetch_add(fc1cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                arrived = (unsigned) __builtin_amdgcn_readfirstlane((int) arrived);
+                asm volatile("" ::: "memory");
+                if ((arrived & 3u) == 3u && 32 * wg < d4) {               // all 32 values are there: quantize_row_q8_0 of the block (as mq_put), by lanes 0..31
+                    const float y = fc1x[lane & 31];
+                    float a = fabsf(y);
+                    a = fmaxf(a, dpp_f32<0x128>(a)); a = fmaxf(a, dpp_f32<0x124>(a)); a = fmaxf(a, dpp_f32<0x122>(a)); a = fmaxf(a, dpp_f32<0x121>(a));
+                    a = fmaxf(a, __shfl_xor(a, 16, 32));
+                    const float dq = a / 127.f, id = a != 0.0f ? 127.f / a : 0.0f;
+                    const unsigned q = (unsigned) (int) rintf(y * id) & 0xffu;
+                    const unsigned w = q | (dpp_u32<0x101>(q) << 8) | (dpp_u32<0x102>(q) << 16) | (dpp_u32<0x103>(q) << 24);
+                    gu64 * eb = mg_edge(A, l, E_HF) + (size_t) wg * 9;
+                    if (lane < 32 && (lane & 3) == 0) gr_store(eb + (lane >> 2), seq, w);
+                    if (lane == 0) gr_store(eb + 8, seq, __float_as_uint(h2f(f2h(dq))));
+                    mg_trace(A, wg == 0 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
+                }
+                if (wave == 3) {
+                    if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
+                    else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+                } else if (wave == 4) {
+                    if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+                    else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+                }
+            }
+        } else
         if (wave == 1 || wave == 2 || (BIG && (wave == 3 || wave == 4))) {        // waves 3, 4 assist (they hold the next layer's out-projection / cross-query rows)
             const bool own = !BIG || wave <= 2;
             bool assisted = false;
@@ -844,12 +972,16 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             }
         }
         // ---------------- P8: FC2 + residual ----------------
+        MG_FRESH();
         {   // the widest hand-off (2d granules)
-            const int qs = mg_slot(wave, MG_EX_HF), sg = mg_seg(Q ? d4 : 2 * d), i0 = qs * sg, i1 = min(Q ? d4 : 2 * d, i0 + sg);
-            if constexpr (Q) { if (qs >= 0) mg_gather_q8<(NP3 == MG_NP3 ? 14 : 8)>(c, mg_edge(A, l, E_HF), i0, i1, lane, xin, d4 >> 5, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1); }
+            const int ng = QB ? 9 * (d4 >> 5) : Q ? d4 : 2 * d;
+            const int qs = mg_slot(wave, QB ? MG_EX_HFQ : MG_EX_HF), sg = mg_seg(ng), i0 = qs * sg, i1 = min(ng, i0 + sg);
+            if constexpr (QB) { if (qs >= 0) mg_gather_qb<3>(c, mg_edge(A, l, E_HF), i0, i1, lane, xin, d4 >> 5, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1); }
+            else if constexpr (Q) { if (qs >= 0) mg_gather_q8<(NP3 == MG_NP3 ? 14 : 8)>(c, mg_edge(A, l, E_HF), i0, i1, lane, xin, d4 >> 5, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1); }
             else if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
         }
         mg_barrier();
+        MG_FRESH();
         mg_trace(A, wg == 0 && wave == 5 && lane == 0, (l * 8 + 5) * 8 + 4, mg_now());
         if (MG_DEFER && (wave == 1 || wave == 2)) {
             if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_d, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
@@ -877,7 +1009,9 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         }
     }
     if (L == 0 && wave >= 1 && wave <= 5) mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+    MG_FRESH();
     mg_final<NP3, NS, Q>(A, c, smem, pf, have_pf, gw, gb, lane, wave);
+#undef MG_FRESH
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -974,8 +1108,20 @@ __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 
         }
 #pragma unroll
         for (int cc = 0; cc < 32; ++cc) if (cc < nl) sumf += (double) prod[cc];
-        if constexpr (Q) gr_store(edge + h * 64 + tid, seq, __float_as_uint((float) sumf));
-        else {
+        if constexpr (Q) {
+            // The head's 64 outputs are two Q8_0 blocks of the out-projection's operand (quantize_row_q8_0, arch/x86/quants.c): quantised
+            // HERE, once, instead of by every consumer - a block leaves as 8 quads + its scale (9 granules instead of 32 F32 values).
+            const float y = (float) sumf;
+            float a = fabsf(y);
+            a = fmaxf(a, dpp_f32<0x128>(a)); a = fmaxf(a, dpp_f32<0x124>(a)); a = fmaxf(a, dpp_f32<0x122>(a)); a = fmaxf(a, dpp_f32<0x121>(a));
+            a = fmaxf(a, __shfl_xor(a, 16, 32));
+            const float dsc = a / 127.f, id = a != 0.0f ? 127.f / a : 0.0f;
+            const unsigned q = (unsigned) (int) rintf(y * id) & 0xffu;
+            const unsigned w = q | (dpp_u32<0x101>(q) << 8) | (dpp_u32<0x102>(q) << 16) | (dpp_u32<0x103>(q) << 24);      // row_shl:1..3: the quad of lanes 4k..4k+3 in lane 4k
+            gu64 * eb = edge + (size_t) (2 * h + (tid >> 5)) * 9;
+            if ((tid & 3) == 0) gr_store(eb + ((tid & 31) >> 2), seq, w);
+            if ((tid & 31) == 0) gr_store(eb + 8, seq, __float_as_uint(h2f(f2h(dsc))));
+        } else {
         const unsigned hv = (unsigned) f2h((float) sumf);
         const unsigned hi = dpp_u32<0x101>(hv);          // row_shl:1: lane i reads lane i+1
         if ((tid & 1) == 0) gr_store(edge + ((h * 64 + tid) >> 1), seq, (hv & 0xffffu) | (hi << 16));
