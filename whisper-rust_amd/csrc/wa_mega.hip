@@ -747,9 +747,10 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = __builtin_amdgcn_readfirstlane(idx_), nG = (int) gridDim.x - 5 * A->n_head;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+    mg_trace(A, wg == 0 && wave == 0 && (threadIdx.x & 63) == 0, (A->n_layer * 8) * 8 + 6, mg_now());        // entry
     unsigned pf[96];
     bool have_pf = false;
-    constexpr bool BIG = NS == 0 && NP3 == MG_NP3;       // d > 768: more row groups per workgroup than prefetching waves - the idle waves assist
+    constexpr bool BIG = NP3 == MG_NP3;       // d > 768: more row groups per workgroup than prefetching waves - the idle waves assist
     // Quantised, d <= 768: the first MLP product is owned by WHOLE Q8_0 blocks - workgroup b < 4d / 32 has rows 32 b .. 32 b + 31, eight per
     // wave 1..4 -, so that the block leaves already quantised (8 quads + scale: 9 granules instead of 32 F32 values, and no consumer
     // quantises it again).  The four waves meet over an LDS counter; the last one to arrive quantises and publishes.
@@ -783,6 +784,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     else if (wave == 5)         t = mg_mk16<Q, 4 * NS>(pf, Ly[0].fc2_w, Ly[0].fc2_d, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
     else if (wave >= 6)         mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);      // held until the final phase
     mg_barrier();                   // the picked token is in LDS for the three embedding waves
+    mg_trace(A, wg == 0 && wave == 0 && lane == 0, (A->n_layer * 8) * 8 + 7, mg_now());
     if (wave >= 3 && wave <= 5) {   // GELU table -> LDS by LDS-DMA (no registers, nothing waits here); first needed by FC1 of layer 0
         const GAS u32x4 * src = (const GAS u32x4 *) A->gelu;
         for (int j = wave - 3; j < 128; j += 3)         // 128 wave-instructions of 64 x 16 bytes
@@ -1453,7 +1455,10 @@ __global__ __launch_bounds__(MG_THREADS) void k_decode_mega(const wa_mega_args A
     int role, idx;                                       // H self-attention + 4 H cross-attention workgroups, the rest stream weights
     mg_role_of((int) gridDim.x, A.n_head, (int) blockIdx.x, role, idx);
     const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();     // = &A (the struct is the only argument)
-    if (role == 0) { if (A.d == 768) mg_role_gemv<2, 24>(Ap, idx); else if (A.d < 768) mg_role_gemv<2, 0>(Ap, idx); else mg_role_gemv<MG_NP3, 0>(Ap, idx); }
+    if (role == 0) {        // compile-time row lengths for the shapes that matter (ggml-small / -base..: d = 768; large: d = 1280): no guards in the products
+        if (A.d == 768) mg_role_gemv<2, 24>(Ap, idx); else if (A.d < 768) mg_role_gemv<2, 0>(Ap, idx);
+        else mg_role_gemv<MG_NP3, 0>(Ap, idx);        // (a d = 1280 instantiation was tried: the 40-step products fully unrolled spill 2300 registers)
+    }
     else if (role == 1) mg_role_self(Ap, idx);
     else                mg_role_cross(Ap, idx);
 }
@@ -1463,7 +1468,10 @@ __global__ __launch_bounds__(MG_THREADS) void k_decode_mega_q(const wa_mega_args
     int role, idx;
     mg_role_of((int) gridDim.x, A.n_head, (int) blockIdx.x, role, idx);
     const mg_kargs Ap = (mg_kargs) __builtin_amdgcn_kernarg_segment_ptr();
-    if (role == 0) { if (A.d == 768) mg_role_gemv<2, 24, true>(Ap, idx); else if (A.d < 768) mg_role_gemv<2, 0, true>(Ap, idx); else mg_role_gemv<MG_NP3, 0, true>(Ap, idx); }
+    if (role == 0) {
+        if (A.d == 768) mg_role_gemv<2, 24, true>(Ap, idx); else if (A.d < 768) mg_role_gemv<2, 0, true>(Ap, idx);
+        else if (A.d == 1280) mg_role_gemv<MG_NP3, 40, true>(Ap, idx); else mg_role_gemv<MG_NP3, 0, true>(Ap, idx);
+    }
     else if (role == 1) mg_role_self<true>(Ap, idx);
     else                mg_role_cross<true>(Ap, idx);
 }
