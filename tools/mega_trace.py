@@ -31,3 +31,23 @@ for l in range(L):
 r = tr[L * 8]
 print("final      in %8.2f (%4d polls)  ready %8.2f  done %8.2f" % (us(r[0]), r[1], us(r[2]), us(r[3])))
 print("entry %8.2f  token picked %8.2f  (kernel start to layer-0 LayerNorm ready: %.2f us)" % (us(r[6]), us(r[7]), -us(r[6])))
+
+# per-workgroup stamps of one layer's P3 -> P4 (MG_WGTRACE_LAYER): how far apart the workgroups are
+flat = np.fromfile("gpurun_out/mega_dbg.bin", dtype=np.uint32)[L * H * 5120:]
+nG = 256 - 5 * H
+w = flat[1024:1024 + 8 * nG].reshape(nG, 8).astype(np.int64)
+w0 = tr[4 * 8 + 2]         # workgroup 0 writes the ordinary slots
+w[0, 0], w[0, 1], w[0, 2], w[0, 4], w[0, 5] = w0[0], w0[1], w0[2], w0[4], w0[5]
+def stat(name, col, rows=slice(None)):
+    v = np.array([us(x) for x in w[rows, col]])
+    v = v[np.isfinite(v)]
+    print("%-28s min %8.2f  median %8.2f  p90 %8.2f  max %8.2f  (argmax wg %d)" % (name, v.min(), np.median(v), np.percentile(v, 90), v.max(), int(np.argmax(v))))
+print("layer 4, all %d GEMV workgroups:" % nG)
+stat("P3 out-projection published", 3); stat("P4 input complete (sweep)", 0); stat("P4 sums", 4); stat("P4 squares", 5); stat("P4 LayerNorm ready", 2); stat("P4 cross query published", 6)
+pub = np.array([us(x) for x in w[:, 3]]); inn = np.array([us(x) for x in w[:, 0]])
+print("last P3 publish -> first / median / last 'input complete': %.2f / %.2f / %.2f us" % (inn.min() - pub.max(), np.median(inn) - pub.max(), inn.max() - pub.max()))
+print("polls per workgroup: median %d max %d" % (np.median(w[:, 1]), w[:, 1].max()))
+f = flat[3000:3003]
+print("cross-attention finish (layer 4, head 0): start %.2f  tree done %.2f  leftovers done %.2f" % (us(f[0]), us(f[1]), us(f[2])))
+f = flat[3004:3007]
+print("self-attention finish  (layer 4, head 0): start %.2f  tree done %.2f  leftovers done %.2f" % (us(f[0]), us(f[1]), us(f[2])))

@@ -134,6 +134,7 @@ __device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int la
 // -------------------------------------------------------------------------------------------------
 // Gathering is shared by SIX waves: the six lowest-numbered waves not in `ex` (the waves that have only just issued a weight
 // prefetch - a poll behind it would wait for those loads first, vmcnt being in order).  Returns the wave's slot or -1.
+#define MG_WGTRACE_LAYER 4
 #define MG_NQ 6
 #define MG_EX_P1 0x20u      /* wave 5 has just prefetched the next FC2 rows */
 #define MG_EX_P4 0x08u      /* wave 3: next out-projection rows */
@@ -846,12 +847,15 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 1) * 8 + 3, mg_now());
+            if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, own && lane == 0, 1024 + wg * 8 + 3, mg_now());
             if (own && !MG_DEFER) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
             else if (assisted) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, 0, lane);
         }
         // ---------------- P4: LayerNorm + cross query ----------------
         MG_FRESH();
-        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l, wg == 0 && wave == 0 ? (l * 8 + 2) * 8 : -1);
+        // (debug: at layer MG_WGTRACE_LAYER every workgroup stamps this phase - the spread over workgroups is what a hand-off waits for)
+        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l,
+                       wave == 0 ? (wg == 0 ? (l * 8 + 2) * 8 : (A->dbg && l == MG_WGTRACE_LAYER ? 1024 + wg * 8 : -1)) : -1);
         MG_FRESH();
         if (MG_DEFER && wave == 3) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
         mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, mg_slot(wave, MG_EX_P7), lane);
@@ -866,6 +870,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 2) * 8 + 3, mg_now());
+            if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, own && lane == 0, 1024 + wg * 8 + 6, mg_now());
             if (QB) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, 32 * wg, 32, 3, lane);      // its eight rows of the block; next needed in P7
             else if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -1033,50 +1038,6 @@ __device__ __forceinline__ mg_att_smem mg_att_carve(unsigned char * base, int ma
     return m;
 }
 
-__device__ __forceinline__ void mg_softmax(const mg_att_smem & M, int n_kv, float lmax, int tid, int lane, int wave, GAS float * dbg = nullptr) {
-    float * sc = M.sc;
-    lmax = wave_max(lmax);
-    if (lane == 0) M.red[wave] = lmax;
-    mg_barrier();
-    float mx = M.red[0];
-#pragma unroll
-    for (int w = 1; w < MG_NW; ++w) mx = fmaxf(mx, M.red[w]);
-    const int n8 = n_kv & ~7;
-    if (dbg) for (int cc = tid; cc < n_kv; cc += MG_THREADS) dbg[cc] = sc[cc];
-    for (int cc = tid; cc < n_kv; cc += MG_THREADS) sc[cc] = cc < n8 ? wa_expf(sc[cc] - mx) : wa_expf_libm(sc[cc] - mx);
-    mg_barrier();
-    for (int g = tid; g < (n8 >> 3); g += MG_THREADS) {
-        const float * v = &sc[g * 8];
-        M.gs[g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
-    }
-    mg_barrier();
-    {
-        double ps = 0.0;
-        const int ng = n8 >> 3;
-        for (int g = tid; g < ng; g += MG_THREADS) ps += (double) M.gs[g];
-        for (int cc = n8 + tid; cc < n_kv; cc += MG_THREADS) ps += (double) sc[cc];
-        ps = wave_sum_d(ps);
-        if (lane == 0) M.redd[wave] = ps;
-        mg_barrier();
-        if (tid == 0) {
-            double sum = 0.0;
-#pragma unroll
-            for (int w = 0; w < MG_NW; ++w) sum += M.redd[w];
-            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
-            const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
-            if (ilo != ihi) {
-                sum = 0.0;
-                for (int g = 0; g < ng; ++g) sum += (double) M.gs[g];
-                for (int cc = n8; cc < n_kv; ++cc) sum += (double) sc[cc];
-                *M.s_inv = (float) (1.0 / sum);
-            } else *M.s_inv = ilo;
-        }
-        mg_barrier();
-    }
-    const float inv = *M.s_inv;
-    for (int cc = tid; cc < n_kv; cc += MG_THREADS) { M.p16[cc] = f2h(sc[cc] * inv); if (dbg) dbg[1536 + cc] = sc[cc] * inv; }
-    mg_barrier();
-}
 
 // one key's score from its two 16-byte pieces (lane a of the key's 4-lane group): k_attn_exact's arithmetic
 __device__ __forceinline__ float mg_score(const u32x4 & ka, const u32x4 & kb, const float (&qa)[8], const float (&qb)[8], float scale) {
@@ -1096,20 +1057,29 @@ __device__ __forceinline__ float mg_score(const u32x4 & ka, const u32x4 & kb, co
 // final tree over the 32 partial-sum chains + F64 leftovers, by threads 0..63 (tid = d_head index); then publish
 template <bool Q = false>                 // Q: the result leaves in F32, one granule per element (the out-projection quantises it from F32)
 __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 * vleft /* [nl][64] */, const wa_f16 * p16, int np, int nl,
-                                               gu64 * edge, int h, unsigned seq, int tid) {
+                                               gu64 * edge, int h, unsigned seq, int tid, mg_kargs A = nullptr, int tslot = -1) {
     if (tid < 64) {
+        if (tslot >= 0) mg_trace(A, tid == 0, tslot, mg_now());
         float s32[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
         double sumf = (double) wa_tree32(s32);
+        if (tslot >= 0) mg_trace(A, tid == 0, tslot + 1, mg_now() + (sumf == 1e300 ? 1u : 0u));
+        // leftover cells (vec.cpp:221-223: F64, index order).  All 32 rows are read at constant offsets - rows >= nl hold stale LDS and are
+        // dropped by the select below - and nl is made opaque: with `cc < nl ? cc : 0` addresses the compiler kept 32 scalar selects
+        // and 32 masks over the layer loop, spilled them, and issued the 64 LDS reads one at a time (1.7 us of the 7 us of a
+        // cross-attention, 1.2 of the self-attention's 3.2).
+        asm volatile("" : "+s"(nl));
         float prod[32];
+        wa_f16 vl[32];
 #pragma unroll
-        for (int cc = 0; cc < 32; ++cc) {
-            const int c2 = cc < nl ? cc : 0;
-            prod[cc] = h2f(vleft[c2 * 64 + tid]) * h2f(p16[np + c2]);
-        }
+        for (int cc = 0; cc < 32; ++cc) vl[cc] = vleft[cc * 64 + tid];
+        __builtin_amdgcn_sched_barrier(0);          // all 32 reads in flight together (the scheduler otherwise funnels them through one register)
 #pragma unroll
-        for (int cc = 0; cc < 32; ++cc) if (cc < nl) sumf += (double) prod[cc];
+        for (int cc = 0; cc < 32; ++cc) { const float pr = h2f(vl[cc]) * h2f((p16 + np)[cc]); prod[cc] = cc < nl ? pr : -0.0f; }       // x + (-0.0) == x for every x, zeros included
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) sumf += (double) prod[cc];
+        if (tslot >= 0) mg_trace(A, tid == 0, tslot + 2, mg_now() + (sumf == 1e300 ? 1u : 0u));
         if constexpr (Q) {
             // The head's 64 outputs are two Q8_0 blocks of the out-projection's operand (quantize_row_q8_0, arch/x86/quants.c): quantised
             // HERE, once, instead of by every consumer - a block leaves as 8 quads + its scale (9 granules instead of 32 F32 values).
@@ -1239,7 +1209,7 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
             for (int i = 0; i < 4; ++i) M.part[(r0 + i) * 64 + lane] = acc[i];
         }
         mg_barrier();
-        mg_attn_finish<Q>(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid);
+        mg_attn_finish<Q>(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid, A, A->dbg && h == 0 && l == MG_WGTRACE_LAYER ? 3004 : -1);
         mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 3, mg_now());
         mg_barrier();
     }
@@ -1438,7 +1408,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             }
             mg_barrier();
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 7, mg_now());
-            mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid);
+            mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid, A, A->dbg && ci == 0 && l == MG_WGTRACE_LAYER ? 3000 : -1);
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 3, mg_now());
         }
         mg_barrier();
