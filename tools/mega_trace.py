@@ -30,6 +30,7 @@ for l in range(L):
         print("L%02d %-10s in %8.2f (%4d polls)  ready %8.2f  pub %8.2f%s" % (l, names[p], us(r[0]), r[1], us(r[2]) if r[2] else 0.0, us(r[3]), extra))
 r = tr[L * 8]
 print("final      in %8.2f (%4d polls)  ready %8.2f  done %8.2f" % (us(r[0]), r[1], us(r[2]), us(r[3])))
+print("final done %.2f us after layer-0 LayerNorm ready" % us(r[3]))
 print("entry %8.2f  token picked %8.2f  (kernel start to layer-0 LayerNorm ready: %.2f us)" % (us(r[6]), us(r[7]), -us(r[6])))
 
 # per-workgroup stamps of one layer's P3 -> P4 (MG_WGTRACE_LAYER): how far apart the workgroups are

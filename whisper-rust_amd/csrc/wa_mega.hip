@@ -136,12 +136,15 @@ __device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int la
 // prefetch - a poll behind it would wait for those loads first, vmcnt being in order).  Returns the wave's slot or -1.
 #define MG_WGTRACE_LAYER 4
 #define MG_NQ 6
-#define MG_EX_P1 0x20u      /* wave 5 has just prefetched the next FC2 rows */
-#define MG_EX_P4 0x08u      /* wave 3: next out-projection rows */
-#define MG_EX_P7 0x08u
+#define MG_EX_P1 (MG_DEFER ? 0x06u : 0x20u)      /* waves 1, 2 have just asked for the next QKV rows (without MG_DEFER: wave 5 for the next FC2 rows) */
+/* With MG_DEFER the fresh requests sit elsewhere: before P4 waves 1, 2 (FC1 rows, asked for after the P3 barrier); before P7 wave 4 (next
+   cross-query rows, after the P6 barrier) - or wave 3 in the quantised whole-block form (its FC1 rows, after its P6 product); before the
+   FC2 gather wave 3 (next out-projection rows, after P7's LayerNorm). */
+#define MG_EX_P4 (MG_DEFER ? 0x06u : 0x08u)      /* (without MG_DEFER wave 3: next out-projection rows) */
+#define MG_EX_P7 (MG_DEFER && !QB ? 0x10u : 0x08u)
 #define MG_EX_AO 0x06u      /* waves 1, 2: FC1 rows */
 #define MG_EX_AO2 0x10u     /* wave 4: next cross-query rows */
-#define MG_EX_HF 0x06u      /* waves 1, 2: next QKV rows */
+#define MG_EX_HF (MG_DEFER ? 0x08u : 0x06u)      /* (without MG_DEFER waves 1, 2: next QKV rows) */
 #define MG_EX_HFQ 0x18u     /* quantised, whole-block FC1: waves 3, 4 have just asked for the next out-projection / cross-query rows */
 #define MG_EX_FINAL 0x20u   /* wave 5: first logits rows */
 __device__ __forceinline__ int mg_slot(int wave, unsigned ex) {
