@@ -52,3 +52,13 @@ f = flat[3000:3003]
 print("cross-attention finish (layer 4, head 0): start %.2f  tree done %.2f  leftovers done %.2f" % (us(f[0]), us(f[1]), us(f[2])))
 f = flat[3004:3007]
 print("self-attention finish  (layer 4, head 0): start %.2f  tree done %.2f  leftovers done %.2f" % (us(f[0]), us(f[1]), us(f[2])))
+
+w = flat[4096:4096 + 8 * nG].reshape(nG, 8).astype(np.int64)
+w0 = tr[4 * 8 + 4]
+w[0, 0], w[0, 1], w[0, 2], w[0, 4], w[0, 5], w[0, 6] = w0[0], w0[1], w0[2], w0[4], w0[5], w0[3]
+w[0, 3] = tr[4 * 8 + 3][3]
+print("layer 4, P6 -> P7:")
+stat("P6 out-projection published", 3); stat("P7 input complete (sweep)", 0); stat("P7 sums", 4); stat("P7 LayerNorm ready", 2); stat("P7 FC1 published (wave 1)", 6)
+hp = np.array([us(x) for x in flat[3100:3100 + H]]); hi = np.array([us(x) for x in flat[3200:3200 + H]])
+print("cross-attention per head: query seen %s" % " ".join("%.2f" % x for x in hi))
+print("cross-attention per head: published  %s" % " ".join("%.2f" % x for x in hp))

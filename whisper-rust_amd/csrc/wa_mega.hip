@@ -904,6 +904,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
             }
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
+            if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, own && lane == 0, 4096 + wg * 8 + 3, mg_now());
             if (QB) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, 32 * wg, 32, 2, lane);
             else if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -916,7 +917,8 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
         MG_FRESH();
         if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
-        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l, wg == 0 && wave == 0 ? (l * 8 + 4) * 8 : -1);
+        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l,
+                       wave == 0 ? (wg == 0 ? (l * 8 + 4) * 8 : (A->dbg && l == MG_WGTRACE_LAYER ? 4096 + wg * 8 : -1)) : -1);
         MG_FRESH();
         if (MG_DEFER && !QB && wave == 3) {
             if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -972,6 +974,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 else mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
             }
             mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
+            if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, wave == 1 && lane == 0, 4096 + wg * 8 + 6, mg_now());
             if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].qkv_w, Ly[l + 1].qkv_d, Ly[l + 1].qkv_b, Ly[l + 1].qkv_s, 3 * d, d, row_qkv, r_qkv, wave - 1, lane);
                 else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
@@ -1308,6 +1311,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             mg_trace(A, ci == 0 && lane == 0, (l * 8 + 7) * 8 + 2, mg_now());
             const unsigned sp = mg_sweep<1>(mg_edge(A, l, E_QC), [&](int) { return lane < 32 ? h * 32 + lane : -1; }, c, lane, v, 2000u + l);
             mg_trace(A, ci == 0 && lane == 0, (l * 8 + 7) * 8 + 0, mg_now()); mg_trace(A, ci == 0 && lane == 0, (l * 8 + 7) * 8 + 1, sp);
+            if (A->dbg && l == MG_WGTRACE_LAYER && w == 0) mg_trace(A, lane == 0, 3200 + h, mg_now());
             if (lane < 32) ((unsigned *) qs)[lane] = v[0];
         }
         mg_barrier();
@@ -1413,6 +1417,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 7, mg_now());
             mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid, A, A->dbg && ci == 0 && l == MG_WGTRACE_LAYER ? 3000 : -1);
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 3, mg_now());
+            if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, tid == 0, 3100 + h, mg_now());
         }
         mg_barrier();
     }
