@@ -62,3 +62,8 @@ stat("P6 out-projection published", 3); stat("P7 input complete (sweep)", 0); st
 hp = np.array([us(x) for x in flat[3100:3100 + H]]); hi = np.array([us(x) for x in flat[3200:3200 + H]])
 print("cross-attention per head: query seen %s" % " ".join("%.2f" % x for x in hi))
 print("cross-attention per head: published  %s" % " ".join("%.2f" % x for x in hp))
+f = flat[3010:3017]
+print("cross-attention (layer 4, head 0, workgroup 0): query in LDS %.2f | scores + wave max done %.2f | barrier %.2f | maxima exchanged %.2f | exp + sums done %.2f | total exchanged %.2f | p16 written + barrier %.2f" % tuple(us(x) for x in f))
+f = flat[3020:3024].astype(np.int64)
+cyc = (int(f[2]) - int(f[0])) & 0xffffffff; wall = (int(f[3]) - int(f[1])) & 0xffffffff
+print("shader clock during the launch: %d cycles in %.2f us = %.0f MHz" % (cyc, wall / 100.0, cyc / (wall / 100.0)))

@@ -735,6 +735,7 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
         }
     }
     mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, (A->n_layer * 8) * 8 + 3, mg_now());
+    if (A->dbg) { mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, 3022, (unsigned) clock64()); mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, 3023, mg_now()); }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -752,6 +753,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     const int wg = __builtin_amdgcn_readfirstlane(idx_), nG = (int) gridDim.x - 5 * A->n_head;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
     mg_trace(A, wg == 0 && wave == 0 && (threadIdx.x & 63) == 0, (A->n_layer * 8) * 8 + 6, mg_now());        // entry
+    if (A->dbg) { mg_trace(A, wg == 0 && wave == 0 && (threadIdx.x & 63) == 0, 3020, (unsigned) clock64()); mg_trace(A, wg == 0 && wave == 0 && (threadIdx.x & 63) == 0, 3021, mg_now()); }
     unsigned pf[96];
     bool have_pf = false;
     constexpr bool BIG = NP3 == MG_NP3;       // d > 768: more row groups per workgroup than prefetching waves - the idle waves assist
@@ -1315,6 +1317,8 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             if (lane < 32) ((unsigned *) qs)[lane] = v[0];
         }
         mg_barrier();
+#define MG_CX(k) do { if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, ci == 0 && tid == 0, 3010 + (k), mg_now()); } while (0)
+        MG_CX(0);
         // ---- scores of the own cells (local index o = 8 s + r  <->  cell 32 s + 8 w + r) ----
         float lmax = -INFINITY;
         {
@@ -1330,7 +1334,9 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
         }
         lmax = wave_max(lmax);
         if (lane == 0) red[wave] = lmax;
+        MG_CX(1);
         mg_barrier();
+        MG_CX(2);
         if (wave == 0) {        // (1) maxima of the four workgroups
             float m = red[0];
 #pragma unroll
@@ -1341,6 +1347,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             float g = lane < 4 ? __uint_as_float(v[0]) : -INFINITY;
             g = fmaxf(g, dpp_f32<0x4e>(g)); g = fmaxf(g, dpp_f32<0xb1>(g));      // max over lanes 0..3
             if (lane == 0) bc[0] = g;
+            MG_CX(3);
         }
         mg_barrier();
         mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 4, mg_now());
@@ -1361,6 +1368,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             ps = wave_sum_d(ps);
             if (lane == 0) redd[wave] = ps;
         }
+        MG_CX(4);
         mg_barrier();
         if (wave == 0) {        // (2) partial sums -> total, certified
             const double ps = ((redd[0] + redd[1]) + (redd[2] + redd[3])) + ((redd[4] + redd[5]) + (redd[6] + redd[7]));
@@ -1378,6 +1386,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
             if (ilo != ihi && lane == 0 && !c.dead) __hip_atomic_store(c.status, (unsigned) WA_MEGA_REDO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) bc[1] = ilo;
+            MG_CX(5);
         }
         mg_barrier();
         mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 5, mg_now());
@@ -1391,6 +1400,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             }
         }
         mg_barrier();
+        MG_CX(6);
         // ---- P V: wave = own chain (cells 32 s + 8 w + wave), lane = d_head index ----
         {
             float acc = 0.0f;
