@@ -103,7 +103,8 @@ __device__ __forceinline__ unsigned mg_now() { return (unsigned) wall_clock64();
 
 // One wave polls the granules idx(0..NPL-1) (idx < 0: none) until every tag equals this launch's sequence number.
 // (Measured: a second, staggered poll in flight per wave makes every hand-off LONGER - 0.377 -> 0.401 ms per token -, longer pauses between
-// polls too (s_sleep 6: 0.384, 14: 0.402), none at all changes nothing: the polls are not what the data waits for, but they do load the fabric.)
+// polls too (s_sleep 6: 0.384, 14: 0.402), none at all changes nothing; a pause before the first poll of the gathers that follow an attention phase cuts their polls by 2-3 x and changes
+// nothing either: the hand-off time is the store-to-load path itself, not contention by the polls.)
 template <int NPL, typename F>
 __device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int lane, unsigned (&v)[NPL], unsigned code) {
     for (unsigned spins = 0;; ++spins) {
