@@ -1068,28 +1068,64 @@ __device__ __forceinline__ float mg_score(const u32x4 & ka, const u32x4 & kb, co
 // final tree over the 32 partial-sum chains + F64 leftovers, by threads 0..63 (tid = d_head index); then publish
 template <bool Q = false>                 // Q: the result leaves in F32, one granule per element (the out-projection quantises it from F32)
 __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 * vleft /* [nl][64] */, const wa_f16 * p16, int np, int nl,
-                                               gu64 * edge, int h, unsigned seq, int tid, mg_kargs A = nullptr, int tslot = -1) {
+                                               gu64 * edge, int h, unsigned seq, int tid, mg_kargs A = nullptr, int tslot = -1,
+                                               double * dbl0 = nullptr, double * dbl1 = nullptr /* [16][64] each: LDS for the split form */) {
+    // Split form (all eight waves call; dbl0 / dbl1 given): the 32 leftover products are spread over waves 1..7 - five cells each, for the
+    // 64 outputs, converted to F64 and parked in LDS - while wave 0 runs the tree; what is left in series is wave 0's 32 F64 additions.
+    // (One wave alone spends 0.7 us on 32 F16 reads, products and quarter-rate conversions per output.)
+    const bool split = dbl0 != nullptr;
+    asm volatile("" : "+s"(nl));
+    if (split && tid >= 64) {            // waves 1..7: five cells each (wave 0 has the tree)
+        const int wv = tid >> 6, o = tid & 63;
+        float nzero = -0.0f;
+        asm volatile("" : "+v"(nzero));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int cc = 5 * (wv - 1) + i;
+            if (cc < 32) {
+                const float pr = fmaf(h2f(vleft[cc * 64 + o]), h2f((p16 + np)[cc]), nzero);
+                (cc < 16 ? dbl0 : dbl1)[(cc & 15) * 64 + o] = (double) (cc < nl ? pr : -0.0f);
+            }
+        }
+    }
+    double sumf = 0.0;
     if (tid < 64) {
         if (tslot >= 0) mg_trace(A, tid == 0, tslot, mg_now());
         float s32[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
-        double sumf = (double) wa_tree32(s32);
+        sumf = (double) wa_tree32(s32);
         if (tslot >= 0) mg_trace(A, tid == 0, tslot + 1, mg_now() + (sumf == 1e300 ? 1u : 0u));
+    }
+    if (split) mg_barrier();
+    if (tid < 64) {
+        if (split) {
+            double dv[32];
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) dv[cc] = (cc < 16 ? dbl0 : dbl1)[(cc & 15) * 64 + tid];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) sumf += dv[cc];          // vec.cpp:221-223: F64, index order
+        } else {
         // leftover cells (vec.cpp:221-223: F64, index order).  All 32 rows are read at constant offsets - rows >= nl hold stale LDS and are
         // dropped by the select below - and nl is made opaque: with `cc < nl ? cc : 0` addresses the compiler kept 32 scalar selects
         // and 32 masks over the layer loop, spilled them, and issued the 64 LDS reads one at a time (1.7 us of the 7 us of a
         // cross-attention, 1.2 of the self-attention's 3.2).
-        asm volatile("" : "+s"(nl));
         float prod[32];
         wa_f16 vl[32];
 #pragma unroll
         for (int cc = 0; cc < 32; ++cc) vl[cc] = vleft[cc * 64 + tid];
         __builtin_amdgcn_sched_barrier(0);          // all 32 reads in flight together (the scheduler otherwise funnels them through one register)
+        float nzero = -0.0f;
+        asm volatile("" : "+v"(nzero));          // (opaque, or the fma is folded back into conversions + a multiplication)
 #pragma unroll
-        for (int cc = 0; cc < 32; ++cc) { const float pr = h2f(vl[cc]) * h2f((p16 + np)[cc]); prod[cc] = cc < nl ? pr : -0.0f; }       // x + (-0.0) == x for every x, zeros included
+        for (int cc = 0; cc < 32; ++cc) {        // the F16 x F16 product is exact in F32: as ONE v_fma_mix_f32 with a -0.0 addend it is the same float as the multiplication
+            const float pr = fmaf(h2f(vl[cc]), h2f((p16 + np)[cc]), nzero);
+            prod[cc] = cc < nl ? pr : -0.0f;     // x + (-0.0) == x for every x, zeros included
+        }
 #pragma unroll
         for (int cc = 0; cc < 32; ++cc) sumf += (double) prod[cc];
+        }
         if (tslot >= 0) mg_trace(A, tid == 0, tslot + 2, mg_now() + (sumf == 1e300 ? 1u : 0u));
         if constexpr (Q) {
             // The head's 64 outputs are two Q8_0 blocks of the out-projection's operand (quantize_row_q8_0, arch/x86/quants.c): quantised
@@ -1220,7 +1256,10 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
             for (int i = 0; i < 4; ++i) M.part[(r0 + i) * 64 + lane] = acc[i];
         }
         mg_barrier();
-        mg_attn_finish<Q>(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid, A, A->dbg && h == 0 && l == MG_WGTRACE_LAYER ? 3004 : -1);
+        // (split form: the two 8 KB behind cell 448 of the K and V copies are free while n_kv <= 448 - the reference's n_text_ctx)
+        const bool room = n_kv <= 448;
+        mg_attn_finish<Q>(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid, A, A->dbg && h == 0 && l == MG_WGTRACE_LAYER ? 3004 : -1,
+                          room ? (double *) (Ks + 448 * 64) : nullptr, room ? (double *) (Vs + 448 * 64) : nullptr);
         mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 3, mg_now());
         mg_barrier();
     }
@@ -1428,7 +1467,8 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             }
             mg_barrier();
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 7, mg_now());
-            mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid, A, A->dbg && ci == 0 && l == MG_WGTRACE_LAYER ? 3000 : -1);
+            mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid, A, A->dbg && ci == 0 && l == MG_WGTRACE_LAYER ? 3000 : -1,
+                              (double *) (smem + 16384), (double *) (smem + 24576));
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 3, mg_now());
             if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, tid == 0, 3100 + h, mg_now());
         }
@@ -1469,7 +1509,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_decode_mega_q(const wa_mega_args
 
 size_t wa_mega_lds_bytes() {
     const size_t s_self  = (size_t) WA_MEGA_MAX_KV * 64 * 2 * 2 + MG_ATT_SMEM(WA_MEGA_MAX_KV);
-    const size_t s_cross = 8192 + 4096 + 1536 + 768 + 64 + 128 + 64 + 32 + 16;
+    const size_t s_cross = 32768;       // 14.9 KB of the role's arrays, then 2 x 8 KB at 16 KB for mg_attn_finish's split form
     const size_t s_gemv  = MG_PICK_OFF;
     size_t m = s_self > s_cross ? s_self : s_cross;
     m = m > s_gemv ? m : s_gemv;
