@@ -251,7 +251,7 @@ static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & 
     const auto & m = ctx.model;
     const auto & hp = m.hp;
     const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
-    if (!st.mega_enabled || n_kv > WA_MEGA_MAX_KV || n_kv < 1 || kv_head < 0 || kv_head >= n_kv || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
+    if (!st.mega_enabled || n_kv > WA_MEGA_KV_ROOM || n_kv < 1 || kv_head < 0 || kv_head >= n_kv || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
     if (m.wtype != 1 && hp.n_text_state > 768) {
         // quantised AND wide (large-v3-q5_0): the one-launch form is bit-exact (tested) but measured slower than the replayed launch
         // sequence (2.78 vs 2.48 ms per token: the 4d-long rows no longer fit the lanes' registers) - it runs only when asked for

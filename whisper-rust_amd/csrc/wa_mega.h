@@ -53,6 +53,7 @@ struct wa_mega_args {
 #define WA_MEGA_REDO 9000u      // status: a soft-max sum could not be certified order-independent - recompute this token with the launch sequence
 #define WA_MEGA_MAX_D 1280
 #define WA_MEGA_MAX_KV 512
+#define WA_MEGA_KV_ROOM 448          // most cells a one-launch step attends over (n_text_ctx of every released model): the LDS rows behind them serve mg_attn_finish
 #define WA_MEGA_MAX_T 1536
 
 #if defined(__HIPCC__)

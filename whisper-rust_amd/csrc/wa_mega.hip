@@ -1068,17 +1068,19 @@ __device__ __forceinline__ float mg_score(const u32x4 & ka, const u32x4 & kb, co
 // final tree over the 32 partial-sum chains + F64 leftovers, by threads 0..63 (tid = d_head index); then publish
 template <bool Q = false>                 // Q: the result leaves in F32, one granule per element (the out-projection quantises it from F32)
 __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 * vleft /* [nl][64] */, const wa_f16 * p16, int np, int nl,
-                                               gu64 * edge, int h, unsigned seq, int tid, mg_kargs A = nullptr, int tslot = -1,
-                                               double * dbl0 = nullptr, double * dbl1 = nullptr /* [16][64] each: LDS for the split form */) {
-    // Split form (all eight waves call; dbl0 / dbl1 given): the 32 leftover products are spread over waves 1..7 - five cells each, for the
-    // 64 outputs, converted to F64 and parked in LDS - while wave 0 runs the tree; what is left in series is wave 0's 32 F64 additions.
-    // (One wave alone spends 0.7 us on 32 F16 reads, products and quarter-rate conversions per output.)
-    const bool split = dbl0 != nullptr;
+                                               gu64 * edge, int h, unsigned seq, int tid, double * dbl0, double * dbl1 /* LDS, [16][64] each */,
+                                               mg_kargs A = nullptr, int tslot = -1) {
+    // All eight waves call.  The leftover cells (vec.cpp:221-223: F64, index order) are spread over waves 1..7 - five cells each, for the 64
+    // outputs: the product as ONE v_fma_mix_f32 (F16 x F16 is exact in F32; with a -0.0 addend it is the multiplication's float), converted
+    // to F64 and parked in LDS - while wave 0 runs the tree; what is left in series is wave 0's 32 F64 additions.  All 32 rows are read at
+    // constant offsets - rows >= nl hold stale LDS and become -0.0, the neutral element of an IEEE sum - and nl is opaque: with
+    // `cc < nl ? cc : 0` addresses the compiler kept 32 scalar selects and 32 masks over the layer loop, spilled them, and issued the LDS
+    // reads one at a time.  (One wave doing all of it: 1.9 us per head; now 0.9.)
     asm volatile("" : "+s"(nl));
-    if (split && tid >= 64) {            // waves 1..7: five cells each (wave 0 has the tree)
+    if (tid >= 64) {
         const int wv = tid >> 6, o = tid & 63;
         float nzero = -0.0f;
-        asm volatile("" : "+v"(nzero));
+        asm volatile("" : "+v"(nzero));          // (opaque, or the fma is folded back into conversions + a multiplication)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int cc = 5 * (wv - 1) + i;
@@ -1097,35 +1099,14 @@ __device__ __forceinline__ void mg_attn_finish(const float * part, const wa_f16 
         sumf = (double) wa_tree32(s32);
         if (tslot >= 0) mg_trace(A, tid == 0, tslot + 1, mg_now() + (sumf == 1e300 ? 1u : 0u));
     }
-    if (split) mg_barrier();
+    mg_barrier();
     if (tid < 64) {
-        if (split) {
-            double dv[32];
+        double dv[32];
 #pragma unroll
-            for (int cc = 0; cc < 32; ++cc) dv[cc] = (cc < 16 ? dbl0 : dbl1)[(cc & 15) * 64 + tid];
-            __builtin_amdgcn_sched_barrier(0);
+        for (int cc = 0; cc < 32; ++cc) dv[cc] = (cc < 16 ? dbl0 : dbl1)[(cc & 15) * 64 + tid];
+        __builtin_amdgcn_sched_barrier(0);       // all 32 reads in flight together
 #pragma unroll
-            for (int cc = 0; cc < 32; ++cc) sumf += dv[cc];          // vec.cpp:221-223: F64, index order
-        } else {
-        // leftover cells (vec.cpp:221-223: F64, index order).  All 32 rows are read at constant offsets - rows >= nl hold stale LDS and are
-        // dropped by the select below - and nl is made opaque: with `cc < nl ? cc : 0` addresses the compiler kept 32 scalar selects
-        // and 32 masks over the layer loop, spilled them, and issued the 64 LDS reads one at a time (1.7 us of the 7 us of a
-        // cross-attention, 1.2 of the self-attention's 3.2).
-        float prod[32];
-        wa_f16 vl[32];
-#pragma unroll
-        for (int cc = 0; cc < 32; ++cc) vl[cc] = vleft[cc * 64 + tid];
-        __builtin_amdgcn_sched_barrier(0);          // all 32 reads in flight together (the scheduler otherwise funnels them through one register)
-        float nzero = -0.0f;
-        asm volatile("" : "+v"(nzero));          // (opaque, or the fma is folded back into conversions + a multiplication)
-#pragma unroll
-        for (int cc = 0; cc < 32; ++cc) {        // the F16 x F16 product is exact in F32: as ONE v_fma_mix_f32 with a -0.0 addend it is the same float as the multiplication
-            const float pr = fmaf(h2f(vl[cc]), h2f((p16 + np)[cc]), nzero);
-            prod[cc] = cc < nl ? pr : -0.0f;     // x + (-0.0) == x for every x, zeros included
-        }
-#pragma unroll
-        for (int cc = 0; cc < 32; ++cc) sumf += (double) prod[cc];
-        }
+        for (int cc = 0; cc < 32; ++cc) sumf += dv[cc];
         if (tslot >= 0) mg_trace(A, tid == 0, tslot + 2, mg_now() + (sumf == 1e300 ? 1u : 0u));
         if constexpr (Q) {
             // The head's 64 outputs are two Q8_0 blocks of the out-projection's operand (quantize_row_q8_0, arch/x86/quants.c): quantised
@@ -1256,10 +1237,9 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
             for (int i = 0; i < 4; ++i) M.part[(r0 + i) * 64 + lane] = acc[i];
         }
         mg_barrier();
-        // (split form: the two 8 KB behind cell 448 of the K and V copies are free while n_kv <= 448 - the reference's n_text_ctx)
-        const bool room = n_kv <= 448;
-        mg_attn_finish<Q>(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid, A, A->dbg && h == 0 && l == MG_WGTRACE_LAYER ? 3004 : -1,
-                          room ? (double *) (Ks + 448 * 64) : nullptr, room ? (double *) (Vs + 448 * 64) : nullptr);
+        // (the 8 KB behind cell WA_MEGA_KV_ROOM of the K and of the V copy are free: the host sends longer contexts through the launch sequence)
+        mg_attn_finish<Q>(M.part, Vs + (size_t) np * 64, M.p16, np, n_kv - np, mg_edge(A, l, E_AO), h, c.seq, tid, (double *) (Ks + WA_MEGA_KV_ROOM * 64),
+                          (double *) (Vs + WA_MEGA_KV_ROOM * 64), A, A->dbg && h == 0 && l == MG_WGTRACE_LAYER ? 3004 : -1);
         mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 3, mg_now());
         mg_barrier();
     }
@@ -1467,8 +1447,8 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
             }
             mg_barrier();
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 7, mg_now());
-            mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid, A, A->dbg && ci == 0 && l == MG_WGTRACE_LAYER ? 3000 : -1,
-                              (double *) (smem + 16384), (double *) (smem + 24576));
+            mg_attn_finish<Q>(part, vleft, pleft - np, np, nl, mg_edge(A, l, E_AO2), h, seq, tid, (double *) (smem + 16384), (double *) (smem + 24576), A,
+                              A->dbg && ci == 0 && l == MG_WGTRACE_LAYER ? 3000 : -1);
             mg_trace(A, ci == 0 && tid == 0, (l * 8 + 7) * 8 + 3, mg_now());
             if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, tid == 0, 3100 + h, mg_now());
         }
