@@ -144,7 +144,7 @@ __device__ __forceinline__ unsigned mg_sweep(gu64 * g, F idx, mg_ctl & c, int la
    cross-query rows, after the P6 barrier) - or wave 3 in the quantised whole-block form (its FC1 rows, after its P6 product); before the
    FC2 gather wave 3 (next out-projection rows, after P7's LayerNorm). */
 #define MG_EX_P4 (MG_DEFER ? 0x06u : 0x08u)      /* (without MG_DEFER wave 3: next out-projection rows) */
-#define MG_EX_P7 (MG_DEFER && !QB ? 0x10u : 0x08u)
+#define MG_EX_P7 (BIGP ? 0x18u : MG_DEFER && !QB ? 0x10u : 0x08u)      /* wide form: waves 3 and 4 have both just asked for their FC1 rows */
 #define MG_EX_AO 0x06u      /* waves 1, 2: FC1 rows */
 #define MG_EX_AO2 0x10u     /* wave 4: next cross-query rows */
 #define MG_EX_HF (MG_DEFER ? 0x08u : 0x06u)      /* (without MG_DEFER waves 1, 2: next QKV rows) */
@@ -764,6 +764,10 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     // wave 1..4 -, so that the block leaves already quantised (8 quads + scale: 9 granules instead of 32 F32 values, and no consumer
     // quantises it again).  The four waves meet over an LDS counter; the last one to arrive quantises and publishes.
     constexpr bool QB = Q && !BIG && MG_DEFER;
+    // Wide models (d > 768), second form of the schedule: FC1 has a prefetched owner for every group (waves 1, 2 | 3, 4 after their P6 products |
+    // 6, 7, which hold no logits rows until the last layer), and waves 3, 4 ask for the first half of their FC2 rows right after FC1 - an assist
+    // that fetches on demand exposes an HBM round trip per group (P7 5.3 -> ~1.5 us, P8 5.9 -> ~4 us per layer on large-v3).
+    constexpr bool BIGP = BIG && MG_DEFER;
     float    * fc1x   = (float *) (smem + WA_MEGA_MAX_D * 4 + 7 * WA_MEGA_MAX_D);           // [32] the block's GELU outputs (behind xq / xd in the xin area)
     unsigned * fc1cnt = (unsigned *) (smem + WA_MEGA_MAX_D * 4 + 7 * WA_MEGA_MAX_D + 128);  // arrivals, never reset: a multiple of 4 after every layer
 
@@ -791,7 +795,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     else if (wave == 3)         t = mg_mk8<Q, NS>(pf, Ly[0].out_w, Ly[0].out_d, Ly[0].out_b, nullptr, d, d, row_d, r_d, 0, lane);
     else if (wave == 4)         t = mg_mk8<Q, NS>(pf, Ly[0].cq_w, Ly[0].cq_d, Ly[0].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
     else if (wave == 5)         t = mg_mk16<Q, 4 * NS>(pf, Ly[0].fc2_w, Ly[0].fc2_d, Ly[0].fc2_b, d, d4, row_d, r_d, 0, lane);
-    else if (wave >= 6)         mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);      // held until the final phase
+    else if (wave >= 6 && !(BIGP && L > 0)) mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);      // held until the final phase (wide form: they own FC1 rows, the logits rows come in the last layer)
     mg_barrier();                   // the picked token is in LDS for the three embedding waves
     mg_trace(A, wg == 0 && wave == 0 && lane == 0, (A->n_layer * 8) * 8 + 7, mg_now());
     if (wave >= 3 && wave <= 5) {   // GELU table -> LDS by LDS-DMA (no registers, nothing waits here); first needed by FC1 of layer 0
@@ -802,6 +806,13 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
 
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
+        // (wide form) what wave 3 / 4 asks for once its FC1 rows are used: the first half of its FC2 rows, or - no such group - the next layer's rows
+        auto big_next = [&](int w) {
+            if (w - 2 < g_d16) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, w - 2, lane);
+            else if (l + 1 >= L) mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, w);
+            else t = w == 3 ? mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane)
+                            : mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
+        };
         // ---------------- P1: LayerNorm + q|k|v ----------------
         MG_FRESH();
         mg_ln3<NP3, Q>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
@@ -866,6 +877,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                        wave == 0 ? (wg == 0 ? (l * 8 + 2) * 8 : (A->dbg && l == MG_WGTRACE_LAYER ? 1024 + wg * 8 : -1)) : -1);
         MG_FRESH();
         if (MG_DEFER && wave == 3) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
+        if (BIGP && wave >= 6 && wave - 2 < g_ff) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 2, lane);      // FC1 groups 4, 5 (the next gather is a cross-attention away)
         mg_ln_params<NP3>(gw, gb, Y.ln3_w, Y.ln3_b, d, mg_slot(wave, MG_EX_P7), lane);
         if (wave == 4 || (BIG && wave == 3)) {        // wave 3 assists (it holds this layer's cross-attention output rows, next needed in P6)
             const bool own = !BIG || wave == 4;
@@ -894,7 +906,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         }
         mg_barrier();
         MG_FRESH();
-        if (MG_DEFER && !QB && wave == 4) {
+        if (MG_DEFER && !QB && !BIGP && wave == 4) {
             if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].cq_w, Ly[l + 1].cq_d, Ly[l + 1].cq_b, nullptr, d, d, row_d, r_d, 0, lane);
             else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
         }
@@ -911,7 +923,10 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             mg_trace(A, wg == 0 && own && lane == 0, (l * 8 + 3) * 8 + 3, mg_now());
             if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, own && lane == 0, 4096 + wg * 8 + 3, mg_now());
             if (QB) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, 32 * wg, 32, 2, lane);
-            else if (own && !MG_DEFER) {
+            else if (BIGP) {                 // FC1 group 2 (wave 3) / 3 (wave 4), used in P7
+                if (wave - 1 < g_ff) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, wave - 1, lane);
+                else big_next(wave);
+            } else if (own && !MG_DEFER) {
                 if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
                 else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
             } else if (assisted) {
@@ -925,7 +940,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l,
                        wave == 0 ? (wg == 0 ? (l * 8 + 4) * 8 : (A->dbg && l == MG_WGTRACE_LAYER ? 4096 + wg * 8 : -1)) : -1);
         MG_FRESH();
-        if (MG_DEFER && !QB && wave == 3) {
+        if (MG_DEFER && !QB && !BIGP && wave == 3) {
             if (l + 1 < L) t = mg_mk8<Q, NS>(pf, Ly[l + 1].out_w, Ly[l + 1].out_d, Ly[l + 1].out_b, nullptr, d, d, row_d, r_d, 0, lane);
             else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
         }
@@ -964,6 +979,22 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                     else mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
                 }
             }
+        } else if (BIGP) {
+            if ((wave >= 1 && wave <= 4) || wave >= 6) {
+                gu64 * eh = mg_edge(A, l, E_HF);
+                for (int grp = wave <= 4 ? wave - 1 : wave - 2; grp < g_ff; grp += 6) {
+                    if (grp >= 6) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane);      // (no released shape has more than six groups)
+                    float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
+                    v = v + t.bias;
+                    float gl = v;                                  // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
+                    if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
+                    if constexpr (Q) { if (t.valid && (lane & 7) == 0) gr_store(eh + t.row, seq, __float_as_uint(gl)); }
+                    else mg_pub_h2(eh, seq, t.valid, t.row, (unsigned) f2h(gl), lane);
+                }
+                mg_trace(A, wg == 0 && wave == 1 && lane == 0, (l * 8 + 4) * 8 + 3, mg_now());
+                if ((wave == 3 || wave == 4) && wave - 1 < g_ff) big_next(wave);       // (without an FC1 group it asked in P6 already)
+                else if (wave >= 6 && l + 1 >= L) mg_prefetch_logits<NS, Q>(A, pf, have_pf, lane, wave);
+            }
         } else
         if (wave == 1 || wave == 2 || (BIG && (wave == 3 || wave == 4))) {        // waves 3, 4 assist (they hold the next layer's out-projection / cross-query rows)
             const bool own = !BIG || wave <= 2;
@@ -993,7 +1024,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         MG_FRESH();
         {   // the widest hand-off (2d granules)
             const int ng = QB ? 9 * (d4 >> 5) : Q ? d4 : 2 * d;
-            const int qs = mg_slot(wave, QB ? MG_EX_HFQ : MG_EX_HF), sg = mg_seg(ng), i0 = qs * sg, i1 = min(ng, i0 + sg);
+            const int qs = mg_slot(wave, QB || BIGP ? MG_EX_HFQ : MG_EX_HF), sg = mg_seg(ng), i0 = qs * sg, i1 = min(ng, i0 + sg);
             if constexpr (QB) { if (qs >= 0) mg_gather_qb<3>(c, mg_edge(A, l, E_HF), i0, i1, lane, xin, d4 >> 5, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1); }
             else if constexpr (Q) { if (qs >= 0) mg_gather_q8<(NP3 == MG_NP3 ? 14 : 8)>(c, mg_edge(A, l, E_HF), i0, i1, lane, xin, d4 >> 5, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1); }
             else if (qs >= 0) mg_gather_h2<7>(c, mg_edge(A, l, E_HF), i0, i1, lane, (unsigned *) xin, 600u + l, A, wg == 0 && wave == 0 ? (l * 8 + 5) * 8 : -1);
@@ -1010,7 +1041,8 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             bool assisted = false;
             gu64 * ex = mg_edge(A, l, E_X3);
             for (int grp = own ? 0 : wave - 2; grp < g_d16; grp += BIG ? 3 : 1) {
-                if (grp >= 1) { t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, grp, lane); assisted = true; }
+                if (grp >= (BIGP ? 3 : 1)) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, grp, lane);      // (wide form: groups 1, 2 were asked for after FC1)
+                if (grp >= 1) assisted = true;
                 float v = mg_do16<Q, 4 * NS>(pf, t, d4 >> 5, xin, lane);
                 v = v + t.bias;
                 if (t.valid && (lane & 15) == MG_RES16(Q)) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
