@@ -314,7 +314,6 @@ def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok
     n % 32 boundaries of the soft-max / P V leftovers; and the one-launch path must actually be the one that ran."""
     amd_lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
     mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)      # "small:q5_0" = the quantised file
-    monkeypatch.setenv("WHISPER_AMD_MEGA_QUANT_WIDE", "1")      # (wide quantised models take the launch sequence by default: exercise the kernel here)
     ctx = wrs.WhisperContext.new_with_params(mp, wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
     monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "1"); ref = ctx.create_state()
     monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "0"); meg = ctx.create_state()

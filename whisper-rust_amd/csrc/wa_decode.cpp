@@ -252,12 +252,6 @@ static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & 
     const auto & hp = m.hp;
     const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
     if (!st.mega_enabled || n_kv > WA_MEGA_KV_ROOM || n_kv < 1 || kv_head < 0 || kv_head >= n_kv || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
-    if (m.wtype != 1 && hp.n_text_state > 768) {
-        // quantised AND wide (large-v3-q5_0): the one-launch form is bit-exact (tested) but measured slower than the replayed launch
-        // sequence (2.78 vs 2.48 ms per token: the 4d-long rows no longer fit the lanes' registers) - it runs only when asked for
-        const bool wide = getenv("WHISPER_AMD_MEGA_QUANT_WIDE") != nullptr;      // (read per call: tests switch it)
-        if (!wide) return false;
-    }
     a.layers = (const wa_mega_layer *) m.d_mega_layers;
     a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
     a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu;
