@@ -592,7 +592,8 @@ __device__ __forceinline__ unsigned mg_pub_h2(gu64 * edge, unsigned seq, bool va
 #define MG_ATT_SMEM(maxkv) (8 * 8 + (maxkv) * 4 + ((maxkv) / 8) * 4 + 32 * 64 * 4 + 8 * 4 + 16 + (maxkv) * 2 + 64 * 2 + 64)      // LDS of the attention scratch (mg_att_carve)
 // LDS of a GEMV workgroup: xf [d] f32 | xin [4d] f16 | LayerNorm partial sums | the F16 GELU table (vec.h:571-585; 128 KB: the
 // FC1 epilogue's look-up is on the critical path of every layer, an L2 round trip there cost ~1 us)
-#define MG_LNRED_OFF ((size_t) WA_MEGA_MAX_D * 4 + (size_t) 4 * WA_MEGA_MAX_D * 2)
+#define MG_XINB_OFF  ((size_t) WA_MEGA_MAX_D * 4 + (size_t) 4 * WA_MEGA_MAX_D * 2)       // FC1's input: a GEMV-input area of its own (see mg_role_gemv)
+#define MG_LNRED_OFF (MG_XINB_OFF + (size_t) 4 * WA_MEGA_MAX_D * 2)
 #define MG_GELU_OFF  (MG_LNRED_OFF + 256)
 #define MG_PICK_OFF  (MG_GELU_OFF + 131072)        // behind every role's LDS (the GEMV role's is the largest)
 #define MG_PICK_BYTES 512
@@ -784,6 +785,10 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
 
     float  * xf  = (float *) smem;                               // [d]   residual row (F32)
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);        // [4d]  GEMV input (F16)
+    // LayerNorm 3's output - FC1's input - lives apart: the gather of FC2's input follows FC1 WITHOUT a barrier (its waves poll while FC1
+    // computes) and a gather wave writes xin as soon as ITS granules are in, which says nothing about this workgroup's own FC1 waves.  With
+    // one area the only protection was timing (other workgroups' results take > 1 us to arrive, workgroups run within ~0.5 us of each other).
+    wa_f16 * xinB = (wa_f16 *) (smem + MG_XINB_OFF);
     const int d = A->d, L = A->n_layer, d4 = 4 * d;
     const int r_qkv = mg_rpw(3 * d, nG), r_d = mg_rpw(d, nG), r_ff = mg_rpw(d4, nG);
     const int row_qkv = wg * r_qkv, row_d = wg * r_d, row_ff = wg * r_ff;
@@ -948,7 +953,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
         MG_FRESH();
         if (l == 0 && wave >= 3 && wave <= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the GELU table has landed (barriers below publish it)
-        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xin, lnred, 500u + l,
+        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X2), gw, gb, mg_slot(wave, MG_EX_P7), lane, xf, xinB, lnred, 500u + l,
                        wave == 0 ? (wg == 0 ? (l * 8 + 4) * 8 : (A->dbg && l == MG_WGTRACE_LAYER ? 4096 + wg * 8 : -1)) : -1);
         MG_FRESH();
         if (MG_DEFER && !QB && !BIGP && wave == 3) {
@@ -959,7 +964,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, mg_slot(wave, MG_EX_FINAL), lane);
         if (QB) {
             if (wave >= 1 && wave <= 4) {
-                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
                 if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
@@ -995,7 +1000,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 gu64 * eh = mg_edge(A, l, E_HF);
                 for (int grp = wave <= 4 ? wave - 1 : wave - 2; grp < g_ff; grp += 6) {
                     if (grp >= 6) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane);      // (no released shape has more than six groups)
-                    float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
+                    float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                     v = v + t.bias;
                     float gl = v;                                  // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
                     if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
@@ -1013,7 +1018,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * eh = mg_edge(A, l, E_HF);
             for (int grp = wave - 1; grp < g_ff; grp += BIG ? 4 : 2) {
                 if (grp >= 2) { t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane); assisted = true; }
-                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
                 if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
