@@ -785,9 +785,12 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
 
     float  * xf  = (float *) smem;                               // [d]   residual row (F32)
     wa_f16 * xin = (wa_f16 *) (smem + WA_MEGA_MAX_D * 4);        // [4d]  GEMV input (F16)
-    // LayerNorm 3's output - FC1's input - lives apart: the gather of FC2's input follows FC1 WITHOUT a barrier (its waves poll while FC1
-    // computes) and a gather wave writes xin as soon as ITS granules are in, which says nothing about this workgroup's own FC1 waves.  With
-    // one area the only protection was timing (other workgroups' results take > 1 us to arrive, workgroups run within ~0.5 us of each other).
+    // The LayerNorms write THEIR outputs (the inputs of q|k|v, the cross query and FC1) into an area of their own; xin takes the gathered
+    // inputs (attention outputs, FC1's output).  A gather follows the previous product WITHOUT a barrier (its waves poll while the product
+    // runs) and a gather wave writes as soon as ITS granules are in, which says nothing about this workgroup's own product waves: with one
+    // area the only protection was timing (other workgroups' results take > 1 us to arrive, workgroups run within ~0.5 us of each other;
+    // 3-6 us where an attention phase sits in between).  Now every writer of an area is separated from its previous readers by the
+    // barriers of a LayerNorm.
     wa_f16 * xinB = (wa_f16 *) (smem + MG_XINB_OFF);
     const int d = A->d, L = A->n_layer, d4 = 4 * d;
     const int r_qkv = mg_rpw(3 * d, nG), r_d = mg_rpw(d, nG), r_ff = mg_rpw(d4, nG);
@@ -831,7 +834,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         };
         // ---------------- P1: LayerNorm + q|k|v ----------------
         MG_FRESH();
-        mg_ln3<NP3, Q>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xin, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
+        mg_ln3<NP3, Q>(A, c, l == 0 ? nullptr : mg_edge(A, l - 1, E_X3), gw, gb, mg_slot(wave, MG_EX_P1), lane, xf, xinB, lnred, 100u + l, wg == 0 && wave == 0 ? (l * 8 + 0) * 8 : -1, pk[0]);
         MG_FRESH();
         mg_ln_params<NP3>(gw, gb, Y.ln2_w, Y.ln2_b, d, mg_slot(wave, MG_EX_P4), lane);
         if (MG_DEFER && l > 0 && wave == 5) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, 0, lane);      // deferred from the previous layer's P8
@@ -844,7 +847,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * eq = mg_edge(A, l, E_QKV);
             for (int grp = wave - 1; grp < g_qkv; grp += BIG ? 4 : 2) {
                 if (grp >= 2) { t = mg_mk8<Q, NS>(pf, Y.qkv_w, Y.qkv_d, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane); assisted = true; }
-                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 v = v * t.scale;
                 const unsigned pk = mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
@@ -889,7 +892,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         // ---------------- P4: LayerNorm + cross query ----------------
         MG_FRESH();
         // (debug: at layer MG_WGTRACE_LAYER every workgroup stamps this phase - the spread over workgroups is what a hand-off waits for)
-        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xin, lnred, 300u + l,
+        mg_ln3<NP3, Q>(A, c, mg_edge(A, l, E_X1), gw, gb, mg_slot(wave, MG_EX_P4), lane, xf, xinB, lnred, 300u + l,
                        wave == 0 ? (wg == 0 ? (l * 8 + 2) * 8 : (A->dbg && l == MG_WGTRACE_LAYER ? 1024 + wg * 8 : -1)) : -1);
         MG_FRESH();
         if (MG_DEFER && wave == 3) t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, 0, lane);
@@ -901,7 +904,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * eq = mg_edge(A, l, E_QC);
             for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
                 if (grp >= 1) { t = mg_mk8<Q, NS>(pf, Y.cq_w, Y.cq_d, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
-                float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
+                float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
             }
