@@ -14,6 +14,7 @@ import ctypes as C
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -330,6 +331,38 @@ def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok
         assert digest(a) == digest(b), "token %d (n_kv %d): max|d| = %g" % (i, len(prompt) + i + 1, float(np.abs(a - b).max()))
         tok = int(np.argmax(a[:50000]))
     assert amd_lib.whisper_amd_mega_enabled(meg.ptr) == 1, "the one-launch step gave up (hand-off time-out) and fell back"
+    ref.free(); meg.free(); ctx.free()
+
+
+@pytest.mark.parametrize("name,n_tok", [("small", 16), ("m1024", 12), ("w1280", 8), ("small:q5_0", 16)])
+def test_one_launch_step_under_stalls(wrs, name, n_tok, monkeypatch):
+    """The same comparison on the test build whose product waves stall at random for ~25 us (libwhisper_chaos.so: wa_mega.hip with
+    -DMG_CHAOS): the rest of the workgroup and of the grid then runs far ahead of the stalled wave, so anything in LDS that relied on
+    how long a product or a hand-off takes shows up as different logits.  (The kernel as it was before the LayerNorm outputs got an
+    LDS area of their own fails this on every token.)"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "whisper-rust_amd", "libwhisper_chaos.so")
+    assert os.path.exists(path), "libwhisper_chaos.so missing: make -C whisper-rust_amd libwhisper_chaos.so (__graft_entry__.build() does)"
+    lib = wrs.load_library(path)
+    wrs.set_log_callback(lib, lambda lvl, txt: sys.stderr.write(txt) if lvl >= 3 else None)
+    lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
+    mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)
+    ctx = wrs.WhisperContext.new_with_params(mp, wrs.WhisperContextParameters(lib), lib=lib)
+    monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "1"); ref = ctx.create_state()
+    monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "0"); meg = ctx.create_state()
+    if lib.whisper_amd_mega_enabled(meg.ptr) != 1:
+        pytest.skip("one-launch step switched off (WHISPER_AMD_NO_MEGA)")
+    pcm = wsynth.synth_audio(480000, 2)
+    sot = ctx.token_sot()
+    prompt = [sot, sot + 1, sot + 102]
+    for st in (ref, meg):
+        st.pcm_to_mel(pcm); st.encode(0); st.decode(prompt, 0)
+    tok = int(np.argmax(ref.get_logits_last(len(prompt))[:50000]))
+    for i in range(n_tok):
+        ref.decode([tok], len(prompt) + i); meg.decode([tok], len(prompt) + i)
+        a = ref.get_logits_last(1); b = meg.get_logits_last(1)
+        assert digest(a) == digest(b), "token %d: max|d| = %g" % (i, float(np.abs(a - b).max()))
+        tok = int(np.argmax(a[:50000]))
+    assert lib.whisper_amd_mega_enabled(meg.ptr) == 1, "the one-launch step gave up under the stalls"
     ref.free(); meg.free(); ctx.free()
 
 

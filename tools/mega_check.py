@@ -10,8 +10,9 @@ import wsynth, whisper_rs as W
 
 name = sys.argv[1] if len(sys.argv) > 1 else "small"
 n_tok = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
-ctx = W.WhisperContext.new_with_params(wsynth.model_path(name), W.WhisperContextParameters(lib), lib=lib)
+lib = W.load_library(os.environ.get("WA_LIB")); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
+mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)      # "small:q5_0" = the quantised file
+ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib), lib=lib)
 os.environ["WHISPER_AMD_NO_MEGA"] = "1"
 ref = ctx.create_state()
 os.environ["WHISPER_AMD_NO_MEGA"] = "0"

@@ -100,6 +100,19 @@ __device__ __forceinline__ void mg_trace(mg_kargs A, bool who, int slot, unsigne
     if (A->dbg && who) ((GAS unsigned *) A->dbg)[(size_t) A->n_layer * A->n_head * 5120 + slot] = v;
 }
 __device__ __forceinline__ unsigned mg_now() { return (unsigned) wall_clock64(); }
+// MG_CHAOS (a test build, tools/chaos_check.sh): some product waves of some workgroups stall for ~25 us right before their product, so that
+// the rest of the workgroup - and the rest of the grid - runs far ahead of them.  Results must not change: nothing in LDS may rely on how long
+// a product or a hand-off takes.
+#ifdef MG_CHAOS
+__device__ __forceinline__ void mg_chaos(unsigned wg, unsigned wave, unsigned l, unsigned phase, unsigned seq) {
+    unsigned h = (wg * 2654435761u) ^ (wave * 40503u) ^ (l * 2246822519u) ^ (phase * 3266489917u) ^ (seq * 668265263u);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    if ((h & 7u) == 0u) for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#define MG_CHAOS_AT(phase) mg_chaos((unsigned) wg, (unsigned) wave, (unsigned) l, (phase), seq)
+#else
+#define MG_CHAOS_AT(phase) do { } while (0)
+#endif
 
 // One wave polls the granules idx(0..NPL-1) (idx < 0: none) until every tag equals this launch's sequence number.
 // (Measured: a second, staggered poll in flight per wave makes every hand-off LONGER - 0.377 -> 0.401 ms per token -, longer pauses between
@@ -847,6 +860,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * eq = mg_edge(A, l, E_QKV);
             for (int grp = wave - 1; grp < g_qkv; grp += BIG ? 4 : 2) {
                 if (grp >= 2) { t = mg_mk8<Q, NS>(pf, Y.qkv_w, Y.qkv_d, Y.qkv_b, Y.qkv_s, 3 * d, d, row_qkv, r_qkv, grp, lane); assisted = true; }
+                MG_CHAOS_AT(1u);
                 float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 v = v * t.scale;
@@ -880,6 +894,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * ex = mg_edge(A, l, E_X1);
             for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
                 if (grp >= 1) { t = mg_mk8<Q, NS>(pf, Y.out_w, Y.out_d, Y.out_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
+                MG_CHAOS_AT(2u);
                 float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
@@ -904,6 +919,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * eq = mg_edge(A, l, E_QC);
             for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
                 if (grp >= 1) { t = mg_mk8<Q, NS>(pf, Y.cq_w, Y.cq_d, Y.cq_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
+                MG_CHAOS_AT(3u);
                 float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 mg_pub_h2(eq, seq, t.valid, t.row, (unsigned) f2h(v), lane);
@@ -935,6 +951,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * ex = mg_edge(A, l, E_X2);
             for (int grp = own ? 0 : 1; grp < g_d8; grp += BIG ? 2 : 1) {
                 if (grp >= 1) { t = mg_mk8<Q, NS>(pf, Y.co_w, Y.co_d, Y.co_b, nullptr, d, d, row_d, r_d, grp, lane); assisted = true; }
+                MG_CHAOS_AT(4u);
                 float v = mg_do8<Q, NS>(pf, t, d >> 5, xin, lane);
                 v = v + t.bias;
                 if (t.valid && (lane & 7) == 0) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
@@ -967,6 +984,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
         else           mg_ln_params<NP3>(gw, gb, A->lnf_w, A->lnf_b, d, mg_slot(wave, MG_EX_FINAL), lane);
         if (QB) {
             if (wave >= 1 && wave <= 4) {
+                MG_CHAOS_AT(5u);
                 float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
@@ -1003,6 +1021,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 gu64 * eh = mg_edge(A, l, E_HF);
                 for (int grp = wave <= 4 ? wave - 1 : wave - 2; grp < g_ff; grp += 6) {
                     if (grp >= 6) t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane);      // (no released shape has more than six groups)
+                    MG_CHAOS_AT(6u);
                     float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                     v = v + t.bias;
                     float gl = v;                                  // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
@@ -1021,6 +1040,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             gu64 * eh = mg_edge(A, l, E_HF);
             for (int grp = wave - 1; grp < g_ff; grp += BIG ? 4 : 2) {
                 if (grp >= 2) { t = mg_mk8<Q, NS>(pf, Y.fc1_w, Y.fc1_d, Y.fc1_b, nullptr, d4, d, row_ff, r_ff, grp, lane); assisted = true; }
+                MG_CHAOS_AT(7u);
                 float v = mg_do8<Q, NS>(pf, t, d >> 5, xinB, lane);
                 v = v + t.bias;
                 float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
@@ -1062,6 +1082,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
             for (int grp = own ? 0 : wave - 2; grp < g_d16; grp += BIG ? 3 : 1) {
                 if (grp >= (BIGP ? 3 : 1)) t = mg_mk16<Q, 4 * NS>(pf, Y.fc2_w, Y.fc2_d, Y.fc2_b, d, d4, row_d, r_d, grp, lane);      // (wide form: groups 1, 2 were asked for after FC1)
                 if (grp >= 1) assisted = true;
+                MG_CHAOS_AT(8u);
                 float v = mg_do16<Q, 4 * NS>(pf, t, d4 >> 5, xin, lane);
                 v = v + t.bias;
                 if (t.valid && (lane & 15) == MG_RES16(Q)) gr_store(ex + t.row, seq, __float_as_uint(v + xf[t.row]));
