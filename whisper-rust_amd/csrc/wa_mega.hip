@@ -110,8 +110,10 @@ __device__ __forceinline__ void mg_chaos(unsigned wg, unsigned wave, unsigned l,
     if ((h & 7u) == 0u) for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
 }
 #define MG_CHAOS_AT(phase) mg_chaos((unsigned) wg, (unsigned) wave, (unsigned) l, (phase), seq)
+#define MG_CHAOS_ID(id, phase, sq) mg_chaos((unsigned) (id), (unsigned) wave, (unsigned) l, (phase), (sq))       /* attention roles: id = 1000 + head / 2000 + workgroup */
 #else
 #define MG_CHAOS_AT(phase) do { } while (0)
+#define MG_CHAOS_ID(id, phase, sq) do { } while (0)
 #endif
 
 // One wave polls the granules idx(0..NPL-1) (idx < 0: none) until every tag equals this launch's sequence number.
@@ -1295,6 +1297,7 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
             mg_barrier();
         }
         mg_trace(A, h == 0 && tid == 0, (l * 8 + 6) * 8 + 5, mg_now());
+        MG_CHAOS_ID(1000 + h, 21u, c.seq);
         // ---- P V: chains r = cell mod 32 (4 per wave), lane = d_head index ----
         const int np = n_kv & ~31, nsteps = np >> 5;
         {
@@ -1413,6 +1416,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
         mg_barrier();
 #define MG_CX(k) do { if (A->dbg && l == MG_WGTRACE_LAYER) mg_trace(A, ci == 0 && tid == 0, 3010 + (k), mg_now()); } while (0)
         MG_CX(0);
+        MG_CHAOS_ID(2000 + ci, 31u, seq);
         // ---- scores of the own cells (local index o = 8 s + r  <->  cell 32 s + 8 w + r) ----
         float lmax = -INFINITY;
         {
@@ -1495,6 +1499,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
         }
         mg_barrier();
         MG_CX(6);
+        MG_CHAOS_ID(2000 + ci, 32u, seq);
         // ---- P V: wave = own chain (cells 32 s + 8 w + wave), lane = d_head index ----
         {
             float acc = 0.0f;
