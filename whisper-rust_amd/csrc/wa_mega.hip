@@ -115,6 +115,12 @@ __device__ __forceinline__ void mg_chaos(unsigned wg, unsigned wave, unsigned l,
 #define MG_CHAOS_AT(phase) do { } while (0)
 #define MG_CHAOS_ID(id, phase, sq) do { } while (0)
 #endif
+// (test build) a workgroup may also START late: whole workgroups stall at the head of their role
+__device__ __forceinline__ void mg_chaos_start(unsigned seq) {
+#ifdef MG_CHAOS
+    mg_chaos(blockIdx.x, 0u, 99u, 41u, seq);
+#endif
+}
 
 // One wave polls the granules idx(0..NPL-1) (idx < 0: none) until every tag equals this launch's sequence number.
 // (Measured: a second, staggered poll in flight per wave makes every hand-off LONGER - 0.377 -> 0.401 ms per token -, longer pauses between
@@ -782,6 +788,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = __builtin_amdgcn_readfirstlane(idx_), nG = (int) gridDim.x - 5 * A->n_head;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+    mg_chaos_start(c.seq);
     mg_trace(A, wg == 0 && wave == 0 && (threadIdx.x & 63) == 0, (A->n_layer * 8) * 8 + 6, mg_now());        // entry
     if (A->dbg) { mg_trace(A, wg == 0 && wave == 0 && (threadIdx.x & 63) == 0, 3020, (unsigned) clock64()); mg_trace(A, wg == 0 && wave == 0 && (threadIdx.x & 63) == 0, 3021, mg_now()); }
     unsigned pf[96];
@@ -1215,6 +1222,7 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = __builtin_amdgcn_readfirstlane(idx_);
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+    mg_chaos_start(c.seq);
 
     wa_f16 * Ks = (wa_f16 *) smem;                                  // [512][64]
     wa_f16 * Vs = Ks + WA_MEGA_MAX_KV * 64;                          // [512][64]
@@ -1356,6 +1364,7 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
     const int ci = __builtin_amdgcn_readfirstlane(idx_);
     const int h = ci >> 2, w = ci & 3;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+    mg_chaos_start(c.seq);
     const unsigned seq = c.seq;
 
     // LDS: part [32][64] f32 | vleft [32][64] f16 | sc [384] f32 | p16 [384] f16 | pleft [32] f16 | qs [64] f16 | red [8] | redd [8] | bc [4]
