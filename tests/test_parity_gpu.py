@@ -366,6 +366,25 @@ def test_one_launch_step_under_stalls(wrs, name, n_tok, monkeypatch):
     ref.free(); meg.free(); ctx.free()
 
 
+def test_full_transcription_under_stalls(wrs, monkeypatch):
+    """whisper_full on the stalled test build: the greedy loop with the device predicting the next token (launches queued back to back,
+    the host reading one launch's logits while the next runs) gives the segments of the launch sequence."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "whisper-rust_amd", "libwhisper_chaos.so")
+    assert os.path.exists(path), "libwhisper_chaos.so missing: make -C whisper-rust_amd libwhisper_chaos.so (__graft_entry__.build() does)"
+    lib = wrs.load_library(path)
+    wrs.set_log_callback(lib, lambda lvl, txt: sys.stderr.write(txt) if lvl >= 3 else None)
+    ctx = wrs.WhisperContext.new_with_params(wsynth.model_path("s128"), wrs.WhisperContextParameters(lib), lib=lib)
+    pcm = wsynth.synth_audio(480000, 3)
+    fp = wrs.FullParams(lib, best_of=1, temperature_inc=0.0)
+    out = {}
+    for nomega in ("1", "0"):
+        monkeypatch.setenv("WHISPER_AMD_NO_MEGA", nomega)
+        st = ctx.create_state(); st.full(fp, pcm); out[nomega] = _segs(st); st.free()
+    _same(out["1"], out["0"])
+    assert sum(len(s_["ids"]) for s_ in out["1"]) > 0
+    ctx.free()
+
+
 def test_one_launch_step_reduced_audio_ctx(wrs, amd_lib, monkeypatch):
     """The one-launch step on reduced audio contexts (streaming windows): T below one 32-cell chain step, not a multiple of 8 / 32,
     a single leftover cell - segments, ids and probabilities identical to the launch sequence."""
