@@ -490,6 +490,17 @@ WHISPER_API int whisper_amd_mega_debug(struct whisper_context * ctx, struct whis
 WHISPER_API int whisper_amd_seq_debug(struct whisper_context * ctx, struct whisper_state * state, int token, int n_past, unsigned * values_out,
                                       float * logits_out);
 
+/* The decode step for 2..8 token rows as ONE launch (wa_rows.hip: beam / best_of steps, small batches, lock-step chunks):
+ * out = { passes served by it, passes sent to the launch sequence after a status word } since the state was created. */
+WHISPER_API void whisper_amd_rows_stats(struct whisper_state * state, long out[2]);
+WHISPER_API int  whisper_amd_rows_enabled(struct whisper_state * state);
+/* Debugging aid (tools/rows_check.py): B identical rows (token, position n_past) of this state through the several-rows step; copies out the
+ * hand-off granules [n_text_layer][8][B][2 * n_text_state] and the logits [B][n_vocab].  Returns the status word (0 = ok), < 0: not available. */
+WHISPER_API int whisper_amd_rows_debug(struct whisper_context * ctx, struct whisper_state * state, int B, int token, int n_past,
+                                       unsigned long long * granules_out, float * logits_out);
+/* Measurement helper (bench.py): average DEVICE time of one B-row step, row i on states[i]'s cells and encoder K / V (null = states[0]). */
+WHISPER_API int whisper_amd_rows_step_probe(struct whisper_context * ctx, struct whisper_state ** states, int B, int n_past, int n_iters, float * ms_per_step);
+
 /* Chunk-parallel transcription on ONE device (the reference's model: one state + thread per chunk, whisper.cpp:7771-7806):
  * runs `n_chunks` independent whisper_full_with_state jobs, each on its own state / HIP stream / host thread; mel, encoder and
  * prompts overlap on the device, and the single-token decode steps of the chunks are served in LOCK STEP - one decoder pass reads

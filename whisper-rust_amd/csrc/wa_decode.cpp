@@ -6,6 +6,7 @@
 #include "wa_internal.h"
 #include "wa_kernels.h"
 #include "wa_mega.h"
+#include "wa_rows.h"
 
 #include <cmath>
 #include <mutex>
@@ -300,6 +301,57 @@ static int mega_step(whisper_context & ctx, whisper_state & st, int token, int p
 }
 
 // -------------------------------------------------------------------------------------------------
+// 2..8 token rows as ONE launch (wa_rows.hip): the rows of a beam / best_of step (one state, cells shared by sequence id: per-row masks)
+// or single tokens of different states decoded in lock step (wa_batcher: per-row K / V).  `bst` owns granules, logits buffer and stream.
+// Returns 1 = done (logits rows in bst.h_logits_pinned), 0 = not applicable / gave up for this pass (caller runs the launch sequence).
+// The slot is taken with try_lock by default: a step that finds another one-launch pass on the device just takes the launch sequence.
+// -------------------------------------------------------------------------------------------------
+static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa_rows_row * rows, int n_out, const int32_t * out_row, int T, int cross_tpad,
+                     uint32_t kv_size, bool wait_slot) {
+    const auto & m = ctx.model;
+    const auto & hp = m.hp;
+    if (B < 1 || B > WA_ROWS_MAX || n_out < 1 || n_out > B || !bst.rows_enabled || m.wtype != 1 || T < 1 || (T >> 5) > 47 || T > cross_tpad) return 0;
+    for (int i = 0; i < B; ++i)
+        if (rows[i].n_kv < 1 || rows[i].n_kv > WA_ROWS_MAXKV || rows[i].kv_head < 0 || rows[i].kv_head >= rows[i].n_kv) return 0;
+    const int n_wg = std::min(m.n_cu, 256);
+    wa_rows_args a;
+    memset(&a, 0, sizeof(a));
+    if (wa_rows_lds_bytes(hp.n_text_state, B, n_wg, &a.slot_bytes) == 0) return 0;
+    if (!wa_rows_prepare(ctx, bst)) return 0;
+    a.layers = (const wa_mega_layer *) m.d_mega_layers;
+    a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
+    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu; a.te_d = nullptr; a.quant = 0;
+    a.kv_layer_stride = (unsigned long long) kv_size * hp.n_text_state;
+    a.cross_layer_stride = (unsigned long long) hp.n_text_head * cross_tpad * 64; a.cross_tpad = cross_tpad; a.T = T;
+    a.granules = bst.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = bst.d_rows_cgr;
+    a.logits = bst.d_logits; a.status = bst.d_rows_status; a.dbg = nullptr;
+    a.kq_scale = pow(float(64), -0.25);
+    a.B = B;
+    for (int i = 0; i < B; ++i) a.rows[i] = rows[i];
+    a.n_out = n_out;
+    for (int i = 0; i < n_out; ++i) a.out_row[i] = out_row ? out_row[i] : i;
+    bst.mega_seq += 1; if (bst.mega_seq == 0) bst.mega_seq = 1;
+    a.seq = bst.mega_seq;
+    hipStream_t s = bst.stream;
+    unsigned * h_status = (unsigned *) (bst.h_logits_pinned + (size_t) WA_MAX_DECODERS * hp.n_vocab);      // (the staging buffer has 64 spare words)
+    std::unique_lock<std::mutex> lk(mega_slot(ctx.device), std::defer_lock);
+    if (wait_slot) lk.lock(); else if (!lk.try_lock()) return 0;
+    if (!wa_launch_decode_rows(s, a, n_wg)) { bst.rows_enabled = false; return 0; }
+    (void) hipMemcpyAsync(bst.h_logits_pinned, bst.d_logits, (size_t) n_out * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
+    (void) hipMemcpyAsync(h_status, bst.d_rows_status, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    if (!WA_HIP_OK(hipStreamSynchronize(s))) { bst.rows_enabled = false; return 0; }
+    lk.unlock();
+    const unsigned status = h_status[0], echo = h_status[1];
+    if (status == 0 && echo == a.seq) { bst.n_rows_steps += 1; return 1; }
+    bst.n_rows_fallback += 1;
+    (void) hipMemsetAsync(bst.d_rows_status, 0, sizeof(unsigned), s);
+    if (status == WA_MEGA_REDO) return 0;          // an uncertifiable soft-max sum (~1e-9 per soft-max): this pass goes through the launch sequence
+    WA_WARN("%s: the %d-row one-launch step gave up (status %u, launch %u / %u) - using the launch sequence from now on\n", __func__, B, status, echo, a.seq);
+    bst.rows_enabled = false;
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
 // host overlap for greedy decoding (wa_full.cpp).  The host's per-token work - the reference's logit rules, an ORDERED F32
 // log-sum-exp over 51 865 logits, libm exp for the timestamp range (whisper.cpp:6149-6489) - costs about a third of a
 // decode step and cannot start before the step's logits exist.  So the device predicts the token itself (wa_mega.hip:
@@ -459,11 +511,22 @@ static void batcher_run(wa_batcher & b) {
             b.h_rowp[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, run[i]->n_kv, run[i]->kv_head };
             n_kv_max = std::max(n_kv_max, run[i]->n_kv);
         }
+        bs.enc_n_ctx = T;
+        // the pass as ONE launch (wa_rows.hip); the launch sequence below stays as the fallback
+        bool served = false;
+        if (bs.rows_enabled) {
+            wa_rows_row rr[WA_MAX_DECODERS];
+            for (int i = 0; i < B; ++i) {
+                whisper_state & ms = *run[i]->st;
+                rr[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, nullptr, run[i]->n_kv, run[i]->kv_head, run[i]->token, run[i]->pos };
+            }
+            served = rows_step(ctx, bs, B, rr, B, nullptr, T, bs.cross_tpad, s0.kv_self.size, true) == 1;
+        }
+        if (!served) {
         (void) hipMemcpyAsync(bs.d_tok, h_tok, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(bs.d_pos, h_pos, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(bs.d_rows, h_rows, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(b.d_rowp, b.h_rowp, B * sizeof(wa_rowptr), hipMemcpyHostToDevice, s);
-        bs.enc_n_ctx = T;
         // (every row's own n_kv comes from its wa_rowptr; the launch-uniform n_kv only picks the kernel variant: <= 512 cells, one block per pair)
         (void) n_kv_max;
         static const bool no_graph = getenv("WHISPER_AMD_NO_GRAPH") != nullptr;
@@ -479,10 +542,16 @@ static void batcher_run(wa_batcher & b) {
             }
             if (b.graph[B]) { b.graph_T[B] = T; b.graph_kv[B] = s0.kv_self.size; } else b.graphs_ok = false;
         }
-        if (b.graph[B] && !no_graph) ok = WA_HIP_OK(hipGraphLaunch(b.graph[B], s));
+        if (b.graph[B] && !no_graph) ok = WA_HIP_OK(hipGraphLaunch(b.graph[B], s)) && ok;
         else decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
+        ok = hipGetLastError() == hipSuccess && ok;
+        // (tests: a pass whose launch failed must not hand out the stale contents of the staging buffer - every member then decodes alone)
+        static const bool test_fail = getenv("WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH") != nullptr;
+        if (test_fail) ok = false;
         (void) hipMemcpyAsync(bs.h_logits_pinned, bs.d_logits, (size_t) B * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
-        ok = WA_HIP_OK(hipStreamSynchronize(s));
+        ok = WA_HIP_OK(hipStreamSynchronize(s)) && ok;
+        if (!ok) b.graphs_ok = false;
+        }
     }
     for (int i = 0; i < B; ++i) {
         if (ok) {
@@ -579,6 +648,16 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     bool done = false, from_batcher = false;
     if (steady && st.batcher && m.wtype == 1) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done && steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && m.wtype == 1 && n_kv <= WA_ROWS_MAXKV) {
+        // one token per live decoder (beam search, best_of, the bench's small batches): all rows in ONE launch (wa_rows.hip)
+        if (need_mask) (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
+        wa_rows_row rr[WA_MAX_DECODERS];
+        for (int i = 0; i < n_tokens; ++i)
+            rr[i] = { kv.k, kv.v, st.d_cross_k, st.d_cross_v, need_mask ? st.d_mask + (size_t) i * n_kv : nullptr, n_kv, kv_head + i, h_tok[i], h_pos[i] };
+        const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
+        static const bool wait_slot = getenv("WHISPER_AMD_ROWS_WAIT") != nullptr;
+        done = rows_step(ctx, st, n_tokens, rr, n_rows, h_rows, T, st.cross_tpad, kv.size, wait_slot) == 1;
+    }
     if (!done) {
     (void) hipMemcpyAsync(st.d_tok,  h_tok,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
     (void) hipMemcpyAsync(st.d_pos,  h_pos,  n_tokens * sizeof(int32_t), hipMemcpyHostToDevice, s);
@@ -729,6 +808,90 @@ extern "C" int whisper_amd_mega_debug(struct whisper_context * ctx, struct whisp
     unsigned status = 0;
     (void) hipMemcpy(&status, st->d_mega_status, 4, hipMemcpyDeviceToHost);
     return (int) status;
+}
+
+// -------------------------------------------------------------------------------------------------
+// the several-rows one-launch step (wa_rows.hip): statistics, a debugging entry and a timing probe
+// -------------------------------------------------------------------------------------------------
+extern "C" void whisper_amd_rows_stats(struct whisper_state * st, long out[2]) {
+    out[0] = st ? st->n_rows_steps : 0; out[1] = st ? st->n_rows_fallback : 0;
+}
+extern "C" int whisper_amd_rows_enabled(struct whisper_state * st) { return st && st->rows_enabled ? 1 : 0; }
+
+static bool rows_probe_args(whisper_context & ctx, whisper_state & own, whisper_state ** sts, int B, const int * tokens, int n_past, wa_rows_args & a) {
+    const auto & m = ctx.model; const auto & hp = m.hp;
+    const int T = own.enc_n_ctx > 0 ? own.enc_n_ctx : hp.n_audio_ctx;
+    memset(&a, 0, sizeof(a));
+    if (B < 1 || B > WA_ROWS_MAX || !own.rows_enabled || n_past < 0 || n_past + 1 > (int) own.kv_self.size || n_past + 1 > WA_ROWS_MAXKV || (T >> 5) > 47) return false;
+    if (wa_rows_lds_bytes(hp.n_text_state, B, std::min(m.n_cu, 256), &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, own)) return false;
+    a.layers = (const wa_mega_layer *) m.d_mega_layers;
+    a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
+    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu;
+    a.kv_layer_stride = (unsigned long long) own.kv_self.size * hp.n_text_state;
+    a.cross_layer_stride = (unsigned long long) hp.n_text_head * own.cross_tpad * 64; a.cross_tpad = own.cross_tpad; a.T = T;
+    a.granules = own.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = own.d_rows_cgr;
+    a.logits = own.d_logits; a.status = own.d_rows_status; a.kq_scale = pow(float(64), -0.25); a.B = B;
+    a.n_out = B; for (int i = 0; i < B; ++i) a.out_row[i] = i;
+    for (int i = 0; i < B; ++i) {
+        whisper_state & ms = sts && sts[i] ? *sts[i] : own;
+        if (ms.kv_self.size != own.kv_self.size || ms.cross_tpad != own.cross_tpad) return false;
+        a.rows[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, nullptr, n_past + 1, n_past, tokens ? tokens[i] : 100, n_past };
+    }
+    return true;
+}
+static void rows_next_seq(whisper_state & st, wa_rows_args & a) { st.mega_seq += 1; if (st.mega_seq == 0) st.mega_seq = 1; a.seq = st.mega_seq; }
+
+// B rows = the SAME (token, position n_past) of this state (cell n_past; identical rows write it identically): every row's granules must then
+// equal the one-row step's (whisper_amd_mega_debug) and every logits row the launch sequence's.  granules_out [layer][8][B][2 d], logits_out [B][n_vocab].
+extern "C" int whisper_amd_rows_debug(struct whisper_context * ctx, struct whisper_state * st, int B, int token, int n_past,
+                                      unsigned long long * granules_out, float * logits_out) {
+    if (!ctx || !st) return -1;
+    if (!WA_HIP_OK(hipSetDevice(ctx->device))) return -1;
+    int toks[WA_ROWS_MAX]; for (int i = 0; i < WA_ROWS_MAX; ++i) toks[i] = token;
+    wa_rows_args a;
+    if (!rows_probe_args(*ctx, *st, nullptr, B, toks, n_past, a)) return -2;
+    rows_next_seq(*st, a);
+    std::lock_guard<std::mutex> lk(mega_slot(ctx->device));
+    if (!wa_launch_decode_rows(st->stream, a, std::min(ctx->model.n_cu, 256))) return -4;
+    if (!WA_HIP_OK(hipStreamSynchronize(st->stream))) return -3;
+    const auto & hp = ctx->model.hp;
+    if (granules_out) (void) hipMemcpy(granules_out, st->d_rows_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * B * a.row_gr * 8, hipMemcpyDeviceToHost);
+    if (logits_out) (void) hipMemcpy(logits_out, st->d_logits, (size_t) B * hp.n_vocab * 4, hipMemcpyDeviceToHost);
+    unsigned status[2] = { 0, 0 };
+    (void) hipMemcpy(status, st->d_rows_status, 8, hipMemcpyDeviceToHost);
+    if (status[0] != 0) (void) hipMemset(st->d_rows_status, 0, 4);
+    if (status[0] == 0 && status[1] != a.seq) return -5;
+    return (int) status[0];
+}
+
+// Measurement helper (bench.py): the B-row step `n_iters` times back to back between two HIP events; row i attends over states[i]'s cells
+// [0, n_past] and encoder K / V (states[i] null = the first state: rows of one chunk, as a beam step).  Cell n_past of every state is overwritten.
+extern "C" int whisper_amd_rows_step_probe(struct whisper_context * ctx, struct whisper_state ** states, int B, int n_past, int n_iters, float * ms_per_step) {
+    if (!ctx || !states || !states[0] || !ms_per_step || n_iters <= 0) return -1;
+    if (!WA_HIP_OK(hipSetDevice(ctx->device))) return -1;
+    whisper_state & own = *states[0];
+    wa_rows_args a;
+    if (!rows_probe_args(*ctx, own, states, B, nullptr, n_past, a)) return -2;
+    const int n_wg = std::min(ctx->model.n_cu, 256);
+    hipStream_t s = own.stream;
+    hipEvent_t e0, e1;
+    if (!WA_HIP_OK(hipEventCreate(&e0)) || !WA_HIP_OK(hipEventCreate(&e1))) return -1;
+    std::lock_guard<std::mutex> lk(mega_slot(ctx->device));
+    rows_next_seq(own, a);
+    if (!wa_launch_decode_rows(s, a, n_wg)) return -4;       // warm-up
+    (void) hipEventRecord(e0, s);
+    for (int i = 0; i < n_iters; ++i) { rows_next_seq(own, a); (void) wa_launch_decode_rows(s, a, n_wg); }
+    (void) hipEventRecord(e1, s);
+    if (!WA_HIP_OK(hipEventSynchronize(e1))) return -3;
+    float ms = 0.f;
+    (void) hipEventElapsedTime(&ms, e0, e1);
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    unsigned status[2] = { 0, 0 };
+    (void) hipMemcpy(status, own.d_rows_status, 8, hipMemcpyDeviceToHost);
+    if (status[0] != 0) { (void) hipMemset(own.d_rows_status, 0, 4); return (int) status[0]; }
+    if (status[1] != a.seq) return -5;
+    *ms_per_step = ms / n_iters;
+    return 0;
 }
 
 extern "C" int whisper_amd_mega_enabled(struct whisper_state * st) { return st && st->mega_enabled ? 1 : 0; }

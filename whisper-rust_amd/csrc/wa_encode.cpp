@@ -7,7 +7,9 @@
 #include "wa_internal.h"
 #include "wa_kernels.h"
 #include "wa_mega.h"
+#include "wa_rows.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -38,6 +40,22 @@ bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells) 
     if (st.h_stage_mask) { (void) hipHostFree(st.h_stage_mask); st.h_stage_mask = nullptr; }
     st.h_mask_cap = st.d_mask_cap;
     if (!WA_HIP_OK(hipHostMalloc((void **) &st.h_stage_mask, st.h_mask_cap))) return false;
+    return true;
+}
+
+// Buffers of the several-rows one-launch decode step (wa_rows.hip), on first use: only states that decode several rows pay for them.
+bool wa_rows_prepare(whisper_context & ctx, whisper_state & st) {
+    if (!st.rows_enabled) return false;
+    if (st.d_rows_gr) return true;
+    const auto & hp = ctx.model.hp;
+    const int dt = hp.n_text_state, Ht = hp.n_text_head;
+    const size_t row_gr = (size_t) (ctx.model.wtype != 1 ? 4 : 2) * dt;
+    if (!dev_alloc(st.d_rows_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * WA_ROWS_MAX * row_gr) ||
+        !dev_alloc(st.d_rows_cgr, (size_t) hp.n_text_layer * WA_ROWS_MAX * Ht * WA_ROWS_CGR) || !dev_alloc(st.d_rows_status, 16)) {
+        dev_free(st.d_rows_gr); dev_free(st.d_rows_cgr); dev_free(st.d_rows_status);
+        st.rows_enabled = false;
+        return false;
+    }
     return true;
 }
 
@@ -95,6 +113,11 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
             if (!dev_alloc(st.d_mega_out2, (size_t) hp.n_vocab + 64) || !dev_alloc(st.d_mega_smask, (size_t) hp.n_vocab / 32 + 2)) return false;
             for (int b = 0; b < 2; ++b)
                 if (!dev_alloc(st.d_mega_rec[b], (size_t) 512 * 8) || !dev_alloc(st.d_mega_ps[b], 8)) return false;
+            {   // the several-rows form shares the one-launch step's preconditions (its buffers come with the first such pass: wa_rows_prepare)
+                const char * r = getenv("WHISPER_AMD_NO_ROWS");
+                int slot = 0;
+                st.rows_enabled = !(r && r[0] == '1') && ctx.model.wtype == 1 && wa_rows_lds_bytes(dt, 2, std::min(ctx.model.n_cu, 256), &slot) != 0;
+            }
             // (the copy stream, events and pinned buffers of the host overlap are created on first use, wa_spec_begin: a state that
             //  only ever runs inside whisper_amd_full_batch keeps ONE stream - extra streams cost the concurrent chunks their overlap)
         }
@@ -134,6 +157,7 @@ void wa_state_release(whisper_state & st) {
     dev_free(st.d_q32a); dev_free(st.d_q32b); dev_free(st.d_q8); dev_free(st.d_q8d);
     dev_free(st.d_mega_gr); dev_free(st.d_mega_cgr); dev_free(st.d_mega_out); st.d_mega_status = nullptr;
     dev_free(st.d_mega_out2); dev_free(st.d_mega_smask);
+    dev_free(st.d_rows_gr); dev_free(st.d_rows_cgr); dev_free(st.d_rows_status);
     for (int b = 0; b < 2; ++b) {
         dev_free(st.d_mega_rec[b]); dev_free(st.d_mega_ps[b]);
         if (st.h_spec[b]) { (void) hipHostFree(st.h_spec[b]); st.h_spec[b] = nullptr; }

@@ -260,6 +260,12 @@ struct whisper_state {
     unsigned * d_mega_smask = nullptr;             // [n_vocab / 32 + 1] per-call suppression bits
     float * h_spec[2] = { nullptr, nullptr };      // pinned [n_vocab + 16]
     hipStream_t copy_stream = nullptr;
+    // the decode step for 2..8 token rows as one launch (wa_rows.hip): hand-off granules [layer][8][8][2d], the cross-attention quarters' exchange
+    // area [layer][8][head][2048], {status, sequence echo}; allocated on first use (wa_rows_prepare)
+    unsigned long long * d_rows_gr = nullptr, * d_rows_cgr = nullptr;
+    unsigned * d_rows_status = nullptr;
+    bool rows_enabled = false;
+    long n_rows_steps = 0, n_rows_fallback = 0;      // passes served by the one-launch form / sent to the launch sequence after a status
     struct wa_batcher * batcher = nullptr;   // set while this state is a member of a whisper_amd_full_batch call (wa_decode.cpp)
     bool spec_owner = false;                 // this state holds its device's one-launch slot (wa_spec_begin .. wa_spec_end)
     hipEvent_t ev_k[2] = { nullptr, nullptr }, ev_c[2] = { nullptr, nullptr };
@@ -318,6 +324,7 @@ void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows);
 bool wa_state_alloc(whisper_context & ctx, whisper_state & st);
 void wa_state_release(whisper_state & st);
 bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells);
+bool wa_rows_prepare(whisper_context & ctx, whisper_state & st);      // buffers of the several-rows one-launch step (wa_encode.cpp); false: not available
 
 std::vector<int> wa_tokenize(const wa_vocab & vocab, const std::string & text);       // wa_api.cpp
 int  wa_full(whisper_context * ctx, whisper_state * st, whisper_full_params params, const float * samples, int n_samples); // wa_full.cpp

@@ -1,0 +1,941 @@
+// wa_rows.hip - the decode step for 2..8 token rows (whisper.cpp:2474-2852, n_tokens = rows) as ONE launch.  Design: wa_rows.h.
+//
+// Phases of a layer (the edges are wa_mega.hip's, one run of granules per token row):
+//   P1  LayerNorm(x) -> q|k|v rows (E_QKV; new key / value also to their KV cells)      P2  self-attention units (row, head)   -> E_AO
+//   P3  out-projection + residual (E_X1)   P4  LayerNorm -> cross query (E_QC)           P5  cross-attention units (row, head, quarter) -> E_AO2
+//   P6  out-projection + residual (E_X2)   P7  LayerNorm -> FC1 + GELU (E_HF)            P8  FC2 + residual (E_X3)
+// then the final LayerNorm and the logits rows.  A product phase = [gather or LayerNorm into LDS] -> barrier -> products; the weight
+// chunk of a phase was requested by wave 7 at the barrier of the phase before (LDS-DMA into the other slot) and is waited for by wave 7
+// alone, right before the barrier that starts the products.
+#include "wa_device.h"
+#include "wa_rows.h"
+#include <algorithm>
+
+typedef unsigned long long u64;
+#define GAS __attribute__((address_space(1)))
+#define LAS __attribute__((address_space(3)))
+typedef GAS u64 gu64;
+typedef GAS unsigned gu32;
+typedef const GAS wa_f16 * gch;
+typedef const GAS float * gcf;
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+typedef const __attribute__((address_space(4))) wa_rows_args * mb_kargs;
+typedef const __attribute__((address_space(4))) wa_mega_layer * mb_layers;
+__device__ __forceinline__ mb_kargs mb_uniform(mb_kargs p) {
+    const unsigned long long v = (unsigned long long) p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+    return (mb_kargs) (((unsigned long long) hi << 32) | lo);
+}
+
+#define MB_THREADS 512
+#define MB_NW 8
+#define MB_NCW 7                  // waves that compute products; wave 7 streams the weights
+#define MB_SPIN_LIMIT 40000u      // polls (~0.5 us each) before a hand-off is declared dead
+#define MB_PAD 64                 // bytes behind every weight row in LDS: consecutive rows start 16 banks apart
+
+enum { E_QKV = 0, E_AO, E_X1, E_QC, E_AO2, E_X2, E_HF, E_X3 };
+
+struct mb_ctl { gu32 * status; unsigned seq; bool dead; };
+
+__device__ __forceinline__ void gr_store(gu64 * g, unsigned seq, unsigned v) {
+    __hip_atomic_store(g, ((u64) seq << 32) | (u64) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gr_load(gu64 * g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) { return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, 0xf, 0xf, true); }
+
+__device__ __forceinline__ void mb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the barrier in front of a product phase: wave 7's LDS-DMA of this phase's weights has landed
+__device__ __forceinline__ void mb_barrier_w(int wave) {
+    if (wave == MB_NW - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mb_barrier();
+}
+
+__device__ __forceinline__ gu64 * mb_edge(mb_kargs A, int layer, int e) {
+    return (gu64 *) A->granules + ((size_t) layer * WA_MEGA_EDGES + e) * ((size_t) A->B * A->row_gr);
+}
+
+// One wave polls the granules idx(0..NPL-1) (idx < 0: none) until every tag equals this launch's sequence number (as wa_mega.hip: mg_sweep).
+template <int NPL, typename F>
+__device__ __forceinline__ void mb_sweep(gu64 * g, F idx, mb_ctl & c, int lane, unsigned (&v)[NPL], unsigned code) {
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int i = idx(k);
+            if (i >= 0) { const u64 x = gr_load(g + i); v[k] = (unsigned) x; ok &= (unsigned) (x >> 32) == c.seq; }
+        }
+        if (__all(ok) || c.dead) return;
+        if ((spins & 127u) == 127u) {
+            const unsigned st = __builtin_amdgcn_readfirstlane(__hip_atomic_load(c.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (st != 0u) { c.dead = true; return; }
+            if (spins >= MB_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(c.status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                c.dead = true;
+                return;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// all 512 threads: `per_row` granules of each of B token rows of `edge` (row b's run starts at b * row_gr), eight per thread and round,
+// handed to store(b, j, value) once valid
+template <typename ST>
+__device__ __forceinline__ void mb_gather(mb_ctl & c, gu64 * edge, int B, int per_row, int row_gr, int tid, int lane, ST store, unsigned code) {
+    const int total = B * per_row;
+    for (int base = 0; base < total; base += MB_THREADS * 8) {
+        unsigned v[8];
+        mb_sweep<8>(edge, [&](int k) { const int i = base + tid + MB_THREADS * k; if (i >= total) return -1; const int b = i / per_row; return b * row_gr + (i - b * per_row); },
+                    c, lane, v, code);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = base + tid + MB_THREADS * k; if (i < total) { const int b = i / per_row; store(b, i - b * per_row, v[k]); } }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// LayerNorm of ONE token row by ONE wave (ops.cpp:3225-3242 semantics as wa_exact.hip: wa_ln_stats - F64 sums in any order, accepted
+// when certified order-independent, else redone in index order): the row comes from granules (or the embeddings), stays in registers,
+// and leaves as F16 in `dst`.  The in-order fallback walks the registers lane by lane (no LDS copy of the row).
+// -------------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ double mb_seq_sum(const float (&xv)[NP], int d, bool squares, float mean) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        for (int j = 0; j < 64; ++j) {
+            const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[k]), j));
+            if (64 * k + j < d) { if (squares) { const float a = x - mean; t += (double) (a * a); } else t += (double) x; }
+        }
+    }
+    return t;
+}
+template <int NP>
+__device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_row /* null: embeddings */, const float * lw, const float * lb, int b, int lane,
+                                          wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code) {
+    const int d = A->d;
+    float xv[NP], gw[NP], gb[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; gw[k] = ((gcf) lw)[ic]; gb[k] = ((gcf) lb)[ic]; }
+    if (edge_row) {
+        unsigned v[NP];
+        mb_sweep<NP>(edge_row, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
+    } else {                    // k_dec_embed: token embedding + positional embedding
+        const gch te = (gch) A->te + (size_t) A->rows[b].token * d;
+        const gcf pe = (gcf) A->pe + (size_t) A->rows[b].pos * d;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? h2f(te[i]) + pe[i] : 0.0f; }
+        if (xres_b) {           // the residual values of the rows this workgroup owns in the d-row products
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k; if (i >= row_d && i < row_d + r_d && i < d) xres_b[i - row_d] = xv[k]; }
+        }
+    }
+    double s = 0.0, a = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
+    s = wave_sum_d(s); a = wave_sum_d(a);
+    float mean, mean_hi;
+    if (!wa_sum_bounds(s, a, d, mean, mean_hi, A->rn_d)) {
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) same &= wa_mean_indifferent(xv[k], mean, mean_hi);
+        if (!__all(same)) { s = mb_seq_sum<NP>(xv, d, false, 0.0f); mean = (float) (s / (double) d); }
+    }
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
+    s2 = wave_sum_d(s2);
+    float variance;
+    if (!wa_sum_certain(s2, s2, d, variance, A->rn_d)) { s2 = mb_seq_sum<NP>(xv, d, true, mean); variance = (float) (s2 / (double) d); }
+    const float scale = 1.0f / sqrtf(variance + A->eps);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int i = lane + 64 * k;
+        float y = xv[k] - mean;
+        y = y * scale;
+        y = y * gw[k];
+        y = y + gb[k];
+        if (i < d) dst[i] = f2h(y);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Weight rows -> LDS by LDS-DMA (wave 7).  The LDS image is rows of `pitch` bytes + MB_PAD, lane-linear in 16-byte cells (an LDS-DMA
+// instruction writes 64 consecutive cells): every lane works out which (row, column) its cell is and reads THAT address; cells of the
+// padding (and behind the last row) read a valid dummy address.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mb_dma_rows(const GAS unsigned char * W, int pitch, int row0, int R, int n_rows_total, unsigned char * slot, int lane) {
+    const int cpr = (pitch >> 4) + (MB_PAD >> 4), total = R * cpr, np = (total + 63) >> 6, cvalid = pitch >> 4;
+    const float inv = 1.0f / (float) cpr;
+    for (int p = 0; p < np; ++p) {
+        const int i = p * 64 + lane;
+        int ri = (int) ((float) i * inv);
+        int cc = i - ri * cpr;
+        if (cc < 0) { ri -= 1; cc += cpr; } else if (cc >= cpr) { ri += 1; cc -= cpr; }
+        int gr = row0 + (ri < R ? ri : R - 1);
+        gr = gr < n_rows_total ? gr : n_rows_total - 1;
+        const GAS unsigned char * src = W + (size_t) gr * pitch + (size_t) (cc < cvalid ? cc : 0) * 16;
+        __builtin_amdgcn_global_load_lds((const GAS void *) src, (LAS void *) (slot + (size_t) p * 1024), 16, 0, 0);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Products in ggml_vec_dot_f16 order (vec.cpp:191-231; as k_gemv_exact / wa_mega.hip: mg_dot8, mg_dot16), weights and activations in LDS,
+// BC token rows per pass over the weight row.
+//   8 lanes per weight row : lane u owns elements 4u..4u+3 of every 32-element step;  results in lanes with u == 0
+//   16 lanes per weight row: lane u owns elements 2u, 2u+1 (the 4d-long rows);          results in lanes with u == 0
+// -------------------------------------------------------------------------------------------------
+template <int BC>
+__device__ __forceinline__ void mb_dot8(const unsigned char * wrow, const wa_f16 * xs, int ldx, int b0, int B, int nsteps, float (&res)[BC]) {
+    float acc[BC][4];
+    const wa_f16 * xb[BC];
+#pragma unroll
+    for (int j = 0; j < BC; ++j) { acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.0f; xb[j] = xs + (size_t) (b0 + j < B ? b0 + j : B - 1) * ldx; }
+#pragma unroll 4
+    for (int s = 0; s < nsteps; ++s) {
+        const half4v w4 = *(const half4v *) (wrow + s * 64);
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+            const half4v x4 = *(const half4v *) (xb[j] + s * 32);
+            acc[j][0] = fmaf((float) w4[0], (float) x4[0], acc[j][0]);
+            acc[j][1] = fmaf((float) w4[1], (float) x4[1], acc[j][1]);
+            acc[j][2] = fmaf((float) w4[2], (float) x4[2], acc[j][2]);
+            acc[j][3] = fmaf((float) w4[3], (float) x4[3], acc[j][3]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BC; ++j) {
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc[j][i];
+            v = v + dpp_f32<0x104>(v);          // row_shl:4  s[j] + s[j+2]
+            v = v + dpp_f32<0x102>(v);          // row_shl:2  (s0+s2) + (s1+s3)
+            t[i] = v + dpp_f32<0x101>(v);       // row_shl:1  a[l] + a[l+4]
+        }
+        res[j] = (t[0] + t[1]) + (t[2] + t[3]);
+    }
+}
+template <int BC>
+__device__ __forceinline__ void mb_dot16(const unsigned char * wrow, const wa_f16 * xs, int ldx, int b0, int B, int nsteps, float (&res)[BC]) {
+    float acc[BC][2];
+    const wa_f16 * xb[BC];
+#pragma unroll
+    for (int j = 0; j < BC; ++j) { acc[j][0] = acc[j][1] = 0.0f; xb[j] = xs + (size_t) (b0 + j < B ? b0 + j : B - 1) * ldx; }
+#pragma unroll 8
+    for (int s = 0; s < nsteps; ++s) {
+        const half2v w2 = *(const half2v *) (wrow + s * 64);
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+            const half2v x2 = *(const half2v *) (xb[j] + s * 32);
+            acc[j][0] = fmaf((float) w2[0], (float) x2[0], acc[j][0]);
+            acc[j][1] = fmaf((float) w2[1], (float) x2[1], acc[j][1]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BC; ++j) {
+        float t[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = acc[j][i];
+            v = v + dpp_f32<0x108>(v);          // row_shl:8  s[j] + s[j+2]
+            v = v + dpp_f32<0x104>(v);          // row_shl:4  (s0+s2) + (s1+s3)
+            t[i] = v + dpp_f32<0x102>(v);       // row_shl:2  a[l] + a[l+4]   -> lane 0: t0,t1  lane 1: t2,t3
+        }
+        const float r = t[0] + t[1];
+        res[j] = r + dpp_f32<0x101>(r);         // (t0+t1) + (t2+t3)
+    }
+}
+
+// The product tasks of one weight chunk (Rc rows starting at matrix row `row_base`, in `slot`): task = (group of 64 / LPR weight rows, sub-batch of
+// the token rows), dealt over the computing waves.  epi(values, first token row, end token row, matrix row, lane holds results, bias, scale) - called
+// by every lane; bias / scale of the row are fetched ahead of the product.
+template <int LPR, int BC, typename EPI>
+__device__ __forceinline__ void mb_products(const unsigned char * slot, int stride, int Rc, int row_base, int N, const float * bias, const float * scale,
+                                            const wa_f16 * xs, int ldx, int K, int B, int wave, int lane, EPI epi) {
+    constexpr int GP = 64 / LPR;
+    const int groups = (Rc + GP - 1) / GP, nsub = (B + BC - 1) / BC, per = (B + nsub - 1) / nsub, ntasks = groups * nsub;
+    const int u = lane & (LPR - 1);
+    for (int t = wave; t < ntasks; t += MB_NCW) {
+        const int g = t / nsub, sb = t - g * nsub, b0 = sb * per, b1 = min(B, b0 + per);
+        const int ri = g * GP + lane / LPR;
+        const bool valid = ri < Rc && row_base + ri < N;
+        const unsigned char * wrow = slot + (size_t) (ri < Rc ? ri : Rc - 1) * stride + u * (LPR == 8 ? 8 : 4);
+        const bool has = valid && u == 0;
+        const float bv = has && bias ? ((gcf) bias)[row_base + ri] : 0.0f, sv = has && scale ? ((gcf) scale)[row_base + ri] : 1.0f;
+        float res[BC];
+        if constexpr (LPR == 8) mb_dot8<BC>(wrow, xs + 4 * u, ldx, b0, B, K >> 5, res);
+        else                    mb_dot16<BC>(wrow, xs + 2 * u, ldx, b0, B, K >> 5, res);
+        epi(res, b0, b1, row_base + ri, has, bv, sv);
+    }
+}
+
+// two F16 results (matrix rows n, n + 1 in lanes 16 j and 16 j + 8; n even) as one granule
+__device__ __forceinline__ unsigned mb_pack_h2(unsigned h) { return (h & 0xffffu) | (dpp_u32<0x108>(h) << 16); }
+
+// -------------------------------------------------------------------------------------------------
+// attention scratch in LDS (aliases the FC2-input area, which holds nothing during an attention phase)
+// -------------------------------------------------------------------------------------------------
+#define MB_ATT_BYTES (32 * 64 * 4 + WA_ROWS_MAXKV * 4 + WA_ROWS_MAXKV * 2 + (WA_ROWS_MAXKV / 8) * 4 + 32 * 64 * 2 + 2048 + 512)
+
+__device__ __forceinline__ float mb_score(const u32x4 & ka, const u32x4 & kb, const float (&qa)[8], const float (&qb)[8], float scale) {
+    const wa_f16 * k8a = (const wa_f16 *) &ka, * k8b = (const wa_f16 *) &kb;
+    float v[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+        float t = fmaf(h2f(k8a[l]), qa[l], 0.0f);
+        t = fmaf(h2f(k8b[l]), qb[l], t);
+        t = t + dpp_f32<0x4e>(t);                // quad_perm [2,3,0,1]: s[j] + s[j+2]
+        v[l] = t + dpp_f32<0xb1>(t);             // quad_perm [1,0,3,2]: (s0+s2) + (s1+s3)
+    }
+    const float t0 = v[0] + v[4], t1 = v[1] + v[5], t2 = v[2] + v[6], t3 = v[3] + v[7];
+    return ((t0 + t1) + (t2 + t3)) * scale;
+}
+
+// the head's 64 outputs from the 32 chain sums + the leftover cells in F64, index order (vec.cpp:221-223), by threads 0..63; published packed
+__device__ __forceinline__ void mb_attn_finish(const float * part, const wa_f16 * vleft /* [nl][64] LDS */, const wa_f16 * pleft /* [nl] */, int nl,
+                                               gu64 * edge_row, int h, unsigned seq, int tid) {
+    if (tid < 64) {
+        float s32[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
+        double sumf = (double) wa_tree32(s32);
+        for (int cc = 0; cc < nl; ++cc) sumf += (double) (h2f(vleft[cc * 64 + tid]) * h2f(pleft[cc]));
+        const unsigned hv = (unsigned) f2h((float) sumf);
+        const unsigned hi = dpp_u32<0x101>(hv);          // row_shl:1: lane i reads lane i + 1
+        if ((tid & 1) == 0) gr_store(edge_row + ((h * 64 + tid) >> 1), seq, (hv & 0xffffu) | (hi << 16));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// unit: self-attention of (token row b, head h) (whisper.cpp:2636-2651; arithmetic of k_attn_exact<1>).  Keys and values of earlier
+// tokens come from the row's own cells in HBM; the cells written by THIS launch - the row's own and those of every other row that shares
+// its cache (earlier tokens of a small batch; other beams, which the mask hides) - arrive as granules, like the query.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float  * part = (float *) area;                                  // [32][64]
+    float  * sc   = (float *) (area + 8192);                         // [MAXKV]
+    wa_f16 * p16  = (wa_f16 *) (area + 8192 + WA_ROWS_MAXKV * 4);    // [MAXKV]
+    float  * gs   = (float *) (area + 8192 + WA_ROWS_MAXKV * 6);     // [MAXKV / 8]
+    wa_f16 * vleft = (wa_f16 *) (area + 8192 + WA_ROWS_MAXKV * 6 + WA_ROWS_MAXKV / 2);      // [32][64]
+    unsigned char * sm = area + 8192 + WA_ROWS_MAXKV * 6 + WA_ROWS_MAXKV / 2 + 4096;
+    wa_f16 * knew = (wa_f16 *) sm;                                   // [8][64]
+    wa_f16 * vnew = (wa_f16 *) (sm + 1024);                          // [8][64]
+    wa_f16 * qs   = (wa_f16 *) (sm + 2048);                          // [64]
+    float  * red  = (float *) (sm + 2048 + 128);                     // [8]
+    double * redd = (double *) (sm + 2048 + 192);                    // [8]
+    float  * s_inv = (float *) (sm + 2048 + 256);
+    int    * ncl  = (int *) (sm + 2048 + 288);                       // [8] cell of row j's new key / value in THIS row's cache, or -1
+    const int d = A->d, B = A->B, n_kv = A->rows[b].n_kv;
+    const gch kp = (gch) A->rows[b].kv_k + (size_t) l * A->kv_layer_stride + h * 64;
+    const gch vp = (gch) A->rows[b].kv_v + (size_t) l * A->kv_layer_stride + h * 64;
+    const GAS int8_t * mrow = (const GAS int8_t *) A->rows[b].mask;
+    if (wave < B) {         // wave j: k | v of row j (two runs of 32 packed granules), and the query when j is this row
+        const bool same = A->rows[wave].kv_k == A->rows[b].kv_k;
+        if (same) {
+            unsigned v[2];
+            gu64 * e = mb_edge(A, l, E_QKV) + (size_t) wave * A->row_gr;
+            mb_sweep<2>(e, [&](int k) {
+                if (k == 0) return (lane < 32 ? (d >> 1) : d) + h * 32 + (lane & 31);
+                return wave == b && lane < 32 ? h * 32 + lane : -1; }, c, lane, v, 1000u + l);
+            if (lane < 32) ((unsigned *) (knew + wave * 64))[lane] = v[0]; else ((unsigned *) (vnew + wave * 64))[lane - 32] = v[0];
+            if (wave == b && lane < 32) ((unsigned *) qs)[lane] = v[1];
+        }
+        if (lane == 0) ncl[wave] = same && A->rows[wave].kv_head < n_kv ? A->rows[wave].kv_head : -1;
+    } else if (lane == 0) ncl[wave] = -1;
+    mb_barrier();
+    int nc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nc[j] = __builtin_amdgcn_readfirstlane(ncl[j]);
+    auto new_of = [&](int cc) { int r = -1;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) if (cc == nc[j]) r = j;
+        return r; };
+    // ---- scores: 4 lanes per key ----
+    float lmax = -INFINITY;
+    {
+        const int a = tid & 3, kslot = tid >> 2;
+        float qa[8], qb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { qa[i] = h2f(qs[8 * a + i]); qb[i] = h2f(qs[32 + 8 * a + i]); }
+        for (int c0 = 0; c0 < n_kv; c0 += (MB_THREADS / 4) * 4) {
+            u32x4 ka[4], kb[4];
+            int8_t mk[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                int cc = c0 + p * (MB_THREADS / 4) + kslot; cc = cc < n_kv ? cc : n_kv - 1;
+                ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 8 * a); kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 32 + 8 * a);
+                mk[p] = mrow ? mrow[cc] : (int8_t) 0;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int cc = c0 + p * (MB_THREADS / 4) + kslot;
+                float r = mb_score(ka[p], kb[p], qa, qb, 1.0f);
+                if (cc < n_kv && new_of(cc) < 0) {       // (a cell written by this launch: below, from its granules)
+                    if (mk[p]) r = -INFINITY;
+                    if (a == 0) sc[cc] = r;
+                    lmax = fmaxf(lmax, r);
+                }
+            }
+        }
+        if (tid < 32) {     // the cells of this launch: 4 lanes per row j
+            const int j = tid >> 2, cc = nc[0] * (j == 0) + nc[1] * (j == 1) + nc[2] * (j == 2) + nc[3] * (j == 3) + nc[4] * (j == 4) + nc[5] * (j == 5) + nc[6] * (j == 6) + nc[7] * (j == 7);
+            const bool act = cc >= 0 && new_of(cc) == j;
+            const u32x4 kna = *(const u32x4 *) (knew + j * 64 + 8 * a), knb = *(const u32x4 *) (knew + j * 64 + 32 + 8 * a);
+            float r = mb_score(kna, knb, qa, qb, 1.0f);
+            if (act) {
+                if (mrow && mrow[cc]) r = -INFINITY;
+                if (a == 0) sc[cc] = r;
+                lmax = fmaxf(lmax, r);
+            }
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    mb_barrier();
+    float mx = red[0];
+#pragma unroll
+    for (int k = 1; k < MB_NW; ++k) mx = fmaxf(mx, red[k]);
+    // ---- soft_max exactly as ops.cpp:4792-4818 + vec.cpp:257-308 (k_attn_exact) ----
+    const int n8 = n_kv & ~7, ng = n8 >> 3;
+    for (int cc = tid; cc < n_kv; cc += MB_THREADS) sc[cc] = cc < n8 ? wa_expf(sc[cc] - mx) : wa_expf_libm(sc[cc] - mx);
+    mb_barrier();
+    for (int g = tid; g < ng; g += MB_THREADS) {
+        const float * v = &sc[g * 8];
+        gs[g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+    }
+    mb_barrier();
+    {
+        double ps = 0.0;
+        for (int g = tid; g < ng; g += MB_THREADS) ps += (double) gs[g];
+        for (int cc = n8 + tid; cc < n_kv; cc += MB_THREADS) ps += (double) sc[cc];
+        ps = wave_sum_d(ps);
+        if (lane == 0) redd[wave] = ps;
+        mb_barrier();
+        if (tid == 0) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < MB_NW; ++w) sum += redd[w];
+            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
+            const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
+            if (ilo != ihi) {       // (~1e-9 per soft-max) the reference's order
+                sum = 0.0;
+                for (int g = 0; g < ng; ++g) sum += (double) gs[g];
+                for (int cc = n8; cc < n_kv; ++cc) sum += (double) sc[cc];
+                *s_inv = (float) (1.0 / sum);
+            } else *s_inv = ilo;
+        }
+        mb_barrier();
+    }
+    const float inv = *s_inv;
+    for (int cc = tid; cc < n_kv; cc += MB_THREADS) p16[cc] = f2h(sc[cc] * inv);
+    const int np = n_kv & ~31, nsteps = np >> 5, nl = n_kv - np;
+    if (tid < 256) {        // the leftover cells' V rows -> LDS
+        const int row = tid >> 3, cc = np + row;
+        if (row < nl) {
+            const int j = new_of(cc);
+            *(u32x4 *) (vleft + (size_t) tid * 8) = j >= 0 ? *(const u32x4 *) (vnew + j * 64 + (tid & 7) * 8) : *(const GAS u32x4 *) (vp + (size_t) cc * d + (tid & 7) * 8);
+        }
+    }
+    mb_barrier();
+    // ---- P V: chains r = cell mod 32 (4 per wave), lane = d_head index ----
+    {
+        float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const int r0 = wave * 4;
+        for (int s0 = 0; s0 < nsteps; s0 += 4) {
+            wa_f16 vv[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sidx = s0 + q < nsteps ? s0 + q : nsteps - 1, cc = sidx * 32 + r0 + i;
+                    vv[q][i] = *(const GAS wa_f16 *) (vp + (size_t) cc * d + lane);
+                    const int j = new_of(cc);       // (wave-uniform)
+                    if (j >= 0) vv[q][i] = vnew[j * 64 + lane];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (s0 + q < nsteps) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(h2f(vv[q][i]), h2f(p16[(s0 + q) * 32 + r0 + i]), acc[i]);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[(r0 + i) * 64 + lane] = acc[i];
+    }
+    mb_barrier();
+    mb_attn_finish(part, vleft, p16 + np, nl, mb_edge(A, l, E_AO) + (size_t) b * A->row_gr, h, c.seq, tid);
+    mb_barrier();
+}
+
+// -------------------------------------------------------------------------------------------------
+// unit: a quarter of the cross-attention of (token row b, head h) over the row's encoder K / V (whisper.cpp:2683-2758); arithmetic and
+// split of wa_mega.hip: mg_role_cross - quarter w owns the cells c with (c mod 32) in [8w, 8w + 8) = whole soft-max groups and whole
+// P V chains; the four quarters exchange maxima, F64 partial sums and chain sums through the (layer, row, head) granule area.
+// -------------------------------------------------------------------------------------------------
+#define MB_CSTEPS 48
+#define MB_CGR_MAX 0
+#define MB_CGR_SUM 8
+#define MB_CGR_PART 64
+
+__device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int w, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned seq = c.seq;
+    float  * part  = (float *) area;                                  // [32][64]
+    wa_f16 * vleft = (wa_f16 *) (area + 8192);                        // [32][64]
+    float  * sc    = (float *) (area + 8192 + 4096);                  // [384]
+    wa_f16 * p16   = (wa_f16 *) (area + 8192 + 4096 + 1536);          // [8][48]
+    wa_f16 * pleft = (wa_f16 *) (area + 8192 + 4096 + 1536 + 768);    // [32]
+    wa_f16 * qs    = (wa_f16 *) (area + 8192 + 4096 + 1536 + 768 + 64);
+    double * redd  = (double *) (area + 8192 + 4096 + 1536 + 768 + 64 + 128);
+    float  * red   = (float *) (area + 8192 + 4096 + 1536 + 768 + 64 + 128 + 64);
+    float  * bc    = red + 8;
+    const int T = A->T, tpad = A->cross_tpad, H = A->n_head;
+    const float kq_scale = A->kq_scale;
+    const int a = tid & 3, ks = tid >> 2;
+    const int np = T & ~31, nsteps = np >> 5, nl = T - np, n8 = T & ~7, ng = n8 >> 3;
+    gu64 * X = (gu64 *) A->cross_gr + (((size_t) l * A->B + b) * H + h) * WA_ROWS_CGR;
+    const gch kp = (gch) A->rows[b].cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
+    const gch vp = (gch) A->rows[b].cross_v + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
+    // own keys, own chain elements, leftover V rows
+    u32x4 ka[3], kb[3];
+    unsigned short vv[MB_CSTEPS];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int o = p * 128 + ks, cc = 32 * (o >> 3) + 8 * w + (o & 7);
+        if (cc < T) { ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 8 * a); kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 32 + 8 * a); }
+    }
+#pragma unroll
+    for (int s = 0; s < MB_CSTEPS; ++s) if (s < nsteps) vv[s] = *(const GAS unsigned short *) (vp + (size_t) (32 * s + 8 * w + wave) * 64 + lane);
+    if (w == 0 && tid < 256) {
+        const int row = tid >> 3;
+        if (row < nl) *(u32x4 *) (vleft + (size_t) tid * 8) = *(const GAS u32x4 *) (vp + (size_t) (np + row) * 64 + (tid & 7) * 8);
+    }
+    if (wave == 0) {
+        unsigned v[1];
+        mb_sweep<1>(mb_edge(A, l, E_QC) + (size_t) b * A->row_gr, [&](int) { return lane < 32 ? h * 32 + lane : -1; }, c, lane, v, 2000u + l);
+        if (lane < 32) ((unsigned *) qs)[lane] = v[0];
+    }
+    mb_barrier();
+    // ---- scores of the own cells (local index o = 8 s + r  <->  cell 32 s + 8 w + r) ----
+    float lmax = -INFINITY;
+    {
+        float qa[8], qb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { qa[i] = h2f(qs[8 * a + i]); qb[i] = h2f(qs[32 + 8 * a + i]); }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int o = p * 128 + ks, cc = 32 * (o >> 3) + 8 * w + (o & 7);
+            const float r = mb_score(ka[p], kb[p], qa, qb, kq_scale);
+            if (cc < T) { if (a == 0) sc[o] = r; lmax = fmaxf(lmax, r); }
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wave] = lmax;
+    mb_barrier();
+    if (wave == 0) {        // (1) maxima of the four quarters
+        float m = red[0];
+#pragma unroll
+        for (int k = 1; k < MB_NW; ++k) m = fmaxf(m, red[k]);
+        if (lane == 0) gr_store(X + MB_CGR_MAX + w, seq, __float_as_uint(m));
+        unsigned v[1];
+        mb_sweep<1>(X + MB_CGR_MAX, [&](int) { return lane < 4 ? lane : -1; }, c, lane, v, 2100u + l);
+        float g = lane < 4 ? __uint_as_float(v[0]) : -INFINITY;
+        g = fmaxf(g, dpp_f32<0x4e>(g)); g = fmaxf(g, dpp_f32<0xb1>(g));      // max over lanes 0..3
+        if (lane == 0) bc[0] = g;
+    }
+    mb_barrier();
+    const float mx = bc[0];
+    // ---- exp, group sums (8-lane tree = ops.cpp's), F64 partial sum: thread = one own cell ----
+    {
+        double ps = 0.0;
+        if (tid < 8 * MB_CSTEPS) {
+            const int g = 4 * (tid >> 3) + w, cc = 8 * g + (tid & 7);
+            const float e = cc < n8 ? wa_expf(sc[tid] - mx) : (cc < T ? wa_expf_libm(sc[tid] - mx) : 0.0f);
+            sc[tid] = e;
+            float t = e + dpp_f32<0x104>(e);
+            t = t + dpp_f32<0x102>(t);
+            t = t + dpp_f32<0x101>(t);
+            if (g < ng) ps = (tid & 7) == 0 ? (double) t : 0.0;
+            else ps = (double) e;
+        }
+        ps = wave_sum_d(ps);
+        if (lane == 0) redd[wave] = ps;
+    }
+    mb_barrier();
+    if (wave == 0) {        // (2) partial sums -> total, certified
+        const double ps = ((redd[0] + redd[1]) + (redd[2] + redd[3])) + ((redd[4] + redd[5]) + (redd[6] + redd[7]));
+        const u64 pb = (u64) __double_as_longlong(ps);
+        if (lane == 0) { gr_store(X + MB_CGR_SUM + 2 * w, seq, (unsigned) pb); gr_store(X + MB_CGR_SUM + 2 * w + 1, seq, (unsigned) (pb >> 32)); }
+        unsigned v[1];
+        mb_sweep<1>(X + MB_CGR_SUM, [&](int) { return lane < 8 ? lane : -1; }, c, lane, v, 2200u + l);
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned lo = __builtin_amdgcn_readlane(v[0], 2 * k), hi = __builtin_amdgcn_readlane(v[0], 2 * k + 1);
+            tot += __longlong_as_double((long long) (((u64) hi << 32) | lo));
+        }
+        const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
+        const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
+        if (ilo != ihi && lane == 0 && !c.dead) __hip_atomic_store(c.status, (unsigned) WA_MEGA_REDO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) bc[1] = ilo;
+    }
+    mb_barrier();
+    const float inv = bc[1];
+    if (tid < 8 * MB_CSTEPS) {
+        const int cc = 32 * (tid >> 3) + 8 * w + (tid & 7);
+        if (cc < T) {
+            const wa_f16 ph = f2h(sc[tid] * inv);
+            p16[(tid & 7) * MB_CSTEPS + (tid >> 3)] = ph;
+            if (cc >= np) { if (w == 0) pleft[cc - np] = ph; else gr_store(X + MB_CGR_PART + (w - 1) * 576 + 512 + (tid & 7), seq, (unsigned) ph); }
+        }
+    }
+    mb_barrier();
+    // ---- P V: wave = own chain (cells 32 s + 8 w + wave), lane = d_head index ----
+    {
+        float acc = 0.0f;
+        half8 pw[MB_CSTEPS / 8];
+#pragma unroll
+        for (int k = 0; k < MB_CSTEPS / 8; ++k) pw[k] = *(const half8 *) (p16 + wave * MB_CSTEPS + 8 * k);
+#pragma unroll
+        for (int s = 0; s < MB_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(vv[s]), (float) pw[s >> 3][s & 7], acc);
+        if (w == 0) part[wave * 64 + lane] = acc;
+        else gr_store(X + MB_CGR_PART + (w - 1) * 576 + wave * 64 + lane, seq, __float_as_uint(acc));
+    }
+    if (w == 0) {           // (3) gather the other three quarters' chain sums and leftover probabilities, finish the head
+        if (wave >= 1 && wave <= 6) {
+            const int ww = (wave - 1) >> 1, half = (wave - 1) & 1;
+            gu64 * src = X + MB_CGR_PART + ww * 576;
+            unsigned v[5];
+            mb_sweep<5>(src, [&](int k) { return k < 4 ? half * 256 + 64 * k + lane : (half == 0 && lane < 8 && 8 * (ww + 1) + lane < nl ? 512 + lane : -1); }, c, lane, v, 2300u + l);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part[(8 * (ww + 1) + 4 * half + k) * 64 + lane] = __uint_as_float(v[k]);
+            if (half == 0 && lane < 8) { const int cc = 8 * (ww + 1) + lane; if (cc < nl) pleft[cc] = (wa_f16) v[4]; }
+        }
+        mb_barrier();
+        mb_attn_finish(part, vleft, pleft, nl, mb_edge(A, l, E_AO2) + (size_t) b * A->row_gr, h, seq, tid);
+    }
+    mb_barrier();
+}
+
+// -------------------------------------------------------------------------------------------------
+// final LayerNorm + logits = token_embedding . x for every token row (whisper.cpp:2820-2835): every workgroup, every wave; the embedding
+// rows stream from HBM into registers (two buffers of 24 steps: the loads of the next piece fly during the current one)
+// -------------------------------------------------------------------------------------------------
+template <int BT>
+__device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /* rows of xs = logits rows */, int lane, int wave) {
+    const int d = A->d, ns = d >> 5, nbat = (ns + 23) / 24, n_vocab = A->n_vocab;
+    const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
+    GAS float * logits = (GAS float *) A->logits;
+    unsigned pfa[48], pfb[48];
+    auto grp = [&](int j) { return wg + nwg * (wave + MB_NW * j); };
+    int n_items = 0;
+    for (int j = 0; grp(j) < NG; ++j) n_items += nbat;
+    auto load = [&](int it, unsigned (&buf)[48]) {
+        const int j = it / nbat, bt = it - j * nbat, row = grp(j) * 8 + (lane >> 3);
+        const gch wrow = (gch) A->te + (size_t) (row < n_vocab ? row : 0) * d + 4 * u;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const int s = bt * 24 + k;
+            if (s < ns) { const u32x2 t = *(const GAS u32x2 *) (wrow + (size_t) s * 32); buf[2 * k] = t.x; buf[2 * k + 1] = t.y; }
+        }
+    };
+    float acc[BT][4];
+    auto one = [&](int it, unsigned (&buf)[48]) {
+        const int j = it / nbat, bt = it - j * nbat;
+        if (bt == 0) {
+#pragma unroll
+            for (int m = 0; m < BT; ++m) acc[m][0] = acc[m][1] = acc[m][2] = acc[m][3] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const int s = bt * 24 + k;
+            if (s < ns) {
+                u32x2 t; t.x = buf[2 * k]; t.y = buf[2 * k + 1];
+                const half4v w4 = __builtin_bit_cast(half4v, t);
+#pragma unroll
+                for (int m = 0; m < BT; ++m) {
+                    const half4v x4 = *(const half4v *) (xs + (size_t) (m < B ? m : B - 1) * d + s * 32 + 4 * u);
+                    acc[m][0] = fmaf((float) w4[0], (float) x4[0], acc[m][0]);
+                    acc[m][1] = fmaf((float) w4[1], (float) x4[1], acc[m][1]);
+                    acc[m][2] = fmaf((float) w4[2], (float) x4[2], acc[m][2]);
+                    acc[m][3] = fmaf((float) w4[3], (float) x4[3], acc[m][3]);
+                }
+            }
+        }
+        if (bt == nbat - 1) {
+            const int row = grp(j) * 8 + (lane >> 3);
+#pragma unroll
+            for (int m = 0; m < BT; ++m) {
+                float t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[m][i];
+                    v = v + dpp_f32<0x104>(v);
+                    v = v + dpp_f32<0x102>(v);
+                    t[i] = v + dpp_f32<0x101>(v);
+                }
+                const float r = (t[0] + t[1]) + (t[2] + t[3]);
+                if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = r;
+            }
+        }
+    };
+    if (n_items > 0) load(0, pfa);
+    for (int it = 0; it < n_items; it += 2) {
+        if (it + 1 < n_items) load(it + 1, pfb);
+        one(it, pfa);
+        if (it + 1 >= n_items) break;
+        if (it + 2 < n_items) load(it + 2, pfa);
+        one(it + 1, pfb);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// the kernel
+// -------------------------------------------------------------------------------------------------
+struct mb_phase { const wa_f16 * W; const float * bias; const float * scale; int N, K, r, rc, nck; };
+
+template <int NP>
+__device__ __forceinline__ void mb_body(mb_kargs A_) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const mb_kargs A = mb_uniform(A_);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    mb_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;
+    const unsigned seq = c.seq;
+    const int d = A->d, L = A->n_layer, B = A->B, H = A->n_head, d4 = 4 * d, RG = A->row_gr;
+    const mb_layers Ly = (mb_layers) A->layers;
+
+    // LDS: xres [8][8] f32 | xinB [B][d] f16 (LayerNorm outputs) | area: xin [B][4d] f16 (gathered inputs) / attention scratch | slot 0 | slot 1
+    float  * xres = (float *) smem;
+    wa_f16 * xinB = (wa_f16 *) (smem + 256);
+    const size_t xinB_bytes = ((size_t) B * d * 2 + 255) & ~(size_t) 255;
+    unsigned char * area = smem + 256 + xinB_bytes;
+    wa_f16 * xin = (wa_f16 *) area;
+    size_t area_bytes = (size_t) B * d4 * 2;
+    if (area_bytes < MB_ATT_BYTES) area_bytes = MB_ATT_BYTES;
+    area_bytes = (area_bytes + 255) & ~(size_t) 255;
+    unsigned char * slot0 = area + area_bytes;
+    const int slot_bytes = A->slot_bytes;
+
+    // rows of every matrix this workgroup owns (an even count, the same for every workgroup: mg_rpw)
+    auto rpw = [&](int N) { const int r = (N + nwg - 1) / nwg; return (r + 1) & ~1; };
+    const int r_qkv = rpw(3 * d), r_d = rpw(d), r_ff = rpw(d4);
+    const int row_qkv = wg * r_qkv, row_d = wg * r_d, row_ff = wg * r_ff;
+    auto phase_of = [&](int l, int p) {
+        const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
+        mb_phase ph;
+        ph.scale = nullptr;
+        if (p == 0)      { ph.W = Y.qkv_w; ph.bias = Y.qkv_b; ph.scale = Y.qkv_s; ph.N = 3 * d; ph.K = d; ph.r = r_qkv; }
+        else if (p == 1) { ph.W = Y.out_w; ph.bias = Y.out_b; ph.N = d; ph.K = d; ph.r = r_d; }
+        else if (p == 2) { ph.W = Y.cq_w;  ph.bias = Y.cq_b;  ph.N = d; ph.K = d; ph.r = r_d; }
+        else if (p == 3) { ph.W = Y.co_w;  ph.bias = Y.co_b;  ph.N = d; ph.K = d; ph.r = r_d; }
+        else if (p == 4) { ph.W = Y.fc1_w; ph.bias = Y.fc1_b; ph.N = d4; ph.K = d; ph.r = r_ff; }
+        else             { ph.W = Y.fc2_w; ph.bias = Y.fc2_b; ph.N = d; ph.K = d4; ph.r = r_d; }
+        const int gp = p == 5 ? 4 : 8, stride = 2 * ph.K + MB_PAD;
+        int rc = (slot_bytes / stride) / gp * gp;
+        const int rmax = (ph.r + gp - 1) / gp * gp;
+        ph.rc = rc > rmax ? rmax : rc;
+        ph.nck = (ph.r + ph.rc - 1) / ph.rc;
+        return ph;
+    };
+    // wave 7: request chunk ck of phase (l, p) into the slot of parity `par`
+    auto request = [&](int l, int p, int ck, int par) {
+        const mb_phase ph = phase_of(l, p);
+        const int row0 = wg * ph.r + ck * ph.rc;
+        if (row0 >= ph.N) return;
+        const int R = min(ph.rc, ph.r - ck * ph.rc);
+        mb_dma_rows((const GAS unsigned char *) ph.W, 2 * ph.K, row0, R, ph.N, slot0 + (size_t) par * slot_bytes, lane);
+    };
+    int par = 0;                 // parity of the chunk the NEXT product phase reads
+    // One product phase: `front` has filled the operand rows in LDS; per chunk: barrier (weights landed, operand visible, previous chunk's
+    // readers done) -> wave 7 requests the next chunk of the whole sequence -> waves 0..6 run the tasks.
+    auto run_phase = [&](int l, int p, auto tasks) {
+        const mb_phase ph = phase_of(l, p);
+        for (int ck = 0; ck < ph.nck; ++ck) {
+            mb_barrier_w(wave);
+            if (wave == MB_NW - 1) {
+                int nl_ = l, np_ = p, nc_ = ck + 1;
+                if (nc_ >= ph.nck) { nc_ = 0; np_ = p + 1; if (np_ >= 6) { np_ = 0; nl_ = l + 1; } }
+                if (nl_ < L) request(nl_, np_, nc_, par ^ 1);
+            } else {
+                const int Rc = min(ph.rc, ph.r - ck * ph.rc);
+                tasks(ph, slot0 + (size_t) par * slot_bytes, wg * ph.r + ck * ph.rc, Rc);
+            }
+            par ^= 1;
+        }
+    };
+
+    if (wave == MB_NW - 1 && L > 0) request(0, 0, 0, 0);
+    for (int l = 0; l < L; ++l) {
+        const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
+        // ---------------- P1: LayerNorm + q|k|v ----------------
+        if (wave < B) mb_ln_row<NP>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, Y.ln1_w, Y.ln1_b, wave, lane, xinB + (size_t) wave * d,
+                                    xres + wave * 8, row_d, r_d, 100u + l);
+        run_phase(l, 0, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+            gu64 * eq = mb_edge(A, l, E_QKV);
+            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, ph.scale, xinB, d, ph.K, B, wave, lane,
+                              [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float scale) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int b = b0 + j;
+                    float v = res[j] + bias;
+                    v = v * scale;
+                    const unsigned pk = mb_pack_h2((unsigned) f2h(v));
+                    if (has && b < b1 && (lane & 15) == 0) {
+                        gr_store(eq + (size_t) b * RG + (n >> 1), seq, pk);
+                        if (n >= d) {       // new key / value also go to the row's KV cell for later tokens
+                            GAS wa_f16 * cell = (n < 2 * d ? (GAS wa_f16 *) A->rows[b].kv_k + (n - d) : (GAS wa_f16 *) A->rows[b].kv_v + (n - 2 * d)) +
+                                                (size_t) l * A->kv_layer_stride + (size_t) A->rows[b].kv_head * d;
+                            *(GAS unsigned *) cell = pk;
+                        }
+                    }
+                }
+            });
+        });
+        // ---------------- P2: self-attention ----------------
+        for (int u = wg; u < B * H; u += nwg) mb_unit_self(A, c, area, l, u / H, u % H, tid);
+        // ---------------- P3: out-projection + residual ----------------
+        mb_gather(c, mb_edge(A, l, E_AO), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 200u + l);
+        auto resid_tasks = [&](int e_out) {
+            return [&, e_out](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+                gu64 * ex = mb_edge(A, l, e_out);
+                mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xin, d4, ph.K, B, wave, lane,
+                                  [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int b = b0 + j;
+                        if (has && b < b1) {
+                            const float v = res[j] + bias;
+                            const float xn = v + xres[b * 8 + (n - row_d)];
+                            gr_store(ex + (size_t) b * RG + n, seq, __float_as_uint(xn));
+                            xres[b * 8 + (n - row_d)] = xn;
+                        }
+                    }
+                });
+            };
+        };
+        run_phase(l, 1, resid_tasks(E_X1));
+        // ---------------- P4: LayerNorm + cross query ----------------
+        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X1) + (size_t) wave * RG, Y.ln2_w, Y.ln2_b, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 300u + l);
+        run_phase(l, 2, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+            gu64 * eq = mb_edge(A, l, E_QC);
+            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xinB, d, ph.K, B, wave, lane,
+                              [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int b = b0 + j;
+                    const float v = res[j] + bias;
+                    const unsigned pk = mb_pack_h2((unsigned) f2h(v));
+                    if (has && b < b1 && (lane & 15) == 0) gr_store(eq + (size_t) b * RG + (n >> 1), seq, pk);
+                }
+            });
+        });
+        // ---------------- P5: cross-attention ----------------
+        for (int u = wg; u < B * H * 4; u += nwg) { const int bh = u >> 2; mb_unit_cross(A, c, area, l, bh / H, bh % H, u & 3, tid); }
+        // ---------------- P6: out-projection + residual ----------------
+        mb_gather(c, mb_edge(A, l, E_AO2), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 400u + l);
+        run_phase(l, 3, resid_tasks(E_X2));
+        // ---------------- P7: LayerNorm + FC1 + GELU ----------------
+        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X2) + (size_t) wave * RG, Y.ln3_w, Y.ln3_b, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 500u + l);
+        run_phase(l, 4, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+            gu64 * eh = mb_edge(A, l, E_HF);
+            const GAS wa_f16 * gelu = (const GAS wa_f16 *) A->gelu;
+            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xinB, d, ph.K, B, wave, lane,
+                              [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
+                float tv[3];                                           // wa_gelu (vec.h:571-585) through the F16 table: the look-ups of the token rows together
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { res[j] = res[j] + bias; tv[j] = h2f(gelu[has ? f2h(res[j]) : 0]); }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int b = b0 + j;
+                    const float v = res[j];
+                    float gl = v;
+                    if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = tv[j];
+                    const unsigned pk = mb_pack_h2((unsigned) f2h(gl));
+                    if (has && b < b1 && (lane & 15) == 0) gr_store(eh + (size_t) b * RG + (n >> 1), seq, pk);
+                }
+            });
+        });
+        // ---------------- P8: FC2 + residual ----------------
+        mb_gather(c, mb_edge(A, l, E_HF), B, d4 >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 600u + l);
+        run_phase(l, 5, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+            gu64 * ex = mb_edge(A, l, E_X3);
+            mb_products<16, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xin, d4, ph.K, B, wave, lane,
+                               [&](float (&res)[2], int b0, int b1, int n, bool has, float bias, float) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int b = b0 + j;
+                    if (has && b < b1) {
+                        const float v = res[j] + bias;
+                        const float xn = v + xres[b * 8 + (n - row_d)];
+                        gr_store(ex + (size_t) b * RG + n, seq, __float_as_uint(xn));
+                        xres[b * 8 + (n - row_d)] = xn;
+                    }
+                }
+            });
+        });
+    }
+    // ---------------- final LayerNorm + logits (of the token rows that want them) ----------------
+    const int n_out = A->n_out;
+    if (wave < n_out) {
+        const int br = A->out_row[wave];
+        mb_ln_row<NP>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, A->lnf_w, A->lnf_b, br, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 3000u);
+    }
+    mb_barrier();
+    if (n_out <= 2) mb_logits<2>(A, xinB, n_out, lane, wave); else if (n_out <= 4) mb_logits<4>(A, xinB, n_out, lane, wave);
+    else if (n_out <= 5) mb_logits<5>(A, xinB, n_out, lane, wave); else mb_logits<8>(A, xinB, n_out, lane, wave);
+    if (wg == 0 && tid == 0) ((GAS unsigned *) A->status)[1] = seq;       // this launch ran (the host accepts a step only with its own number here)
+}
+
+__global__ __launch_bounds__(MB_THREADS) void k_decode_rows(const wa_rows_args A) {
+    const mb_kargs Ap = (mb_kargs) __builtin_amdgcn_kernarg_segment_ptr();
+    if (A.d <= 768) mb_body<12>(Ap); else if (A.d <= 1024) mb_body<16>(Ap); else mb_body<20>(Ap);
+}
+
+size_t wa_rows_lds_bytes(int d, int B, int n_wg, int * slot_bytes) {
+    if (B < 1 || B > WA_ROWS_MAX || d < 64 || d > WA_MEGA_MAX_D || (d & 127) != 0 || n_wg < 1) return 0;
+    const size_t xinB_bytes = ((size_t) B * d * 2 + 255) & ~(size_t) 255;
+    size_t area = (size_t) B * 4 * d * 2;
+    if (area < MB_ATT_BYTES) area = MB_ATT_BYTES;
+    area = (area + 255) & ~(size_t) 255;
+    const size_t fixed = 256 + xinB_bytes + area;
+    auto rpw = [&](int N) { const int r = (N + n_wg - 1) / n_wg; return (r + 1) & ~1; };
+    if (rpw(d) > 8) return 0;                       // (xres holds 8 residual values per token row)
+    // a slot holds at least one task group of every phase; the whole chunk of a phase when there is room (fewer barriers)
+    const size_t need_min = std::max((size_t) 8 * (2 * d + MB_PAD), (size_t) 4 * (8 * d + MB_PAD));
+    size_t want = 0;
+    want = std::max(want, (size_t) ((rpw(3 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
+    want = std::max(want, (size_t) ((rpw(4 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
+    want = std::max(want, (size_t) ((rpw(d) + 3) / 4 * 4) * (8 * d + MB_PAD));
+    const size_t total_max = 160 * 1024;
+    if (fixed + 2 * (need_min + 1024) > total_max) return 0;
+    size_t slot = std::min(want, (total_max - fixed) / 2 - 1024);
+    slot = (slot + 1023) & ~(size_t) 1023;          // whole LDS-DMA pieces
+    if (fixed + 2 * slot > total_max) slot -= 1024;
+    if (slot < need_min) return 0;
+    if (slot_bytes) *slot_bytes = (int) slot;
+    return fixed + 2 * slot;
+}
+
+bool wa_launch_decode_rows(hipStream_t s, const wa_rows_args & a, int n_wg) {
+    int slot = 0;
+    const size_t lds = wa_rows_lds_bytes(a.d, a.B, n_wg, &slot);
+    if (lds == 0 || slot != a.slot_bytes || a.quant) return false;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    static bool attr_set[64] = {};
+    if (!attr_set[dev & 63]) {
+        if (hipFuncSetAttribute((const void *) k_decode_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(k_decode_rows, dim3(n_wg), dim3(MB_THREADS), lds, s, a);
+    return hipGetLastError() == hipSuccess;
+}
