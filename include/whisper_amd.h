@@ -510,6 +510,8 @@ WHISPER_API int whisper_amd_full_batch(struct whisper_context * ctx, struct whis
                                        struct whisper_full_params params, const float * const * samples, const int * n_samples);
 /* how the last whisper_amd_full_batch call on this context decoded: lock-step passes and the token rows they served */
 WHISPER_API void whisper_amd_batch_stats(struct whisper_context * ctx, long * steps, long * rows);
+/* ... and how many of those passes were ONE launch (wa_rows.hip) rather than the launch sequence */
+WHISPER_API long whisper_amd_batch_one_launch(struct whisper_context * ctx);
 
 #ifdef __cplusplus
 }

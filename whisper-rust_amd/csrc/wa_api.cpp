@@ -63,6 +63,7 @@ void whisper_amd_abi_sizes(size_t out[6]) {
 
 // how the last whisper_amd_full_batch call on this context decoded: lock-step passes and the token rows they served
 void whisper_amd_batch_stats(struct whisper_context * ctx, long * steps, long * rows) { if (ctx) { *steps = ctx->batch_steps; *rows = ctx->batch_rows; } }
+long whisper_amd_batch_one_launch(struct whisper_context * ctx) { return ctx ? ctx->batch_one_launch : 0; }
 
 } // extern "C"
 
@@ -579,16 +580,17 @@ int whisper_full(struct whisper_context * ctx, struct whisper_full_params params
     return whisper_full_with_state(ctx, ctx->state, params, samples, n_samples);
 }
 // Lock-step decode groups for chunks transcribed together on one device (whisper_amd_full_batch, whisper_full_parallel): groups of
-// WHISPER_AMD_BATCH_GROUP chunks (default 4) share a decoder pass (wa_decode.cpp: wa_batcher); the groups' passes run concurrently on
-// their own streams - a pass is a chain of short latency-bound launches, so two 4-row passes side by side finish sooner than one 8-row
-// pass after the other (measured: 8 chunks 488x real time as one group, 589x as two).
+// WHISPER_AMD_BATCH_GROUP chunks share a decoder pass (wa_decode.cpp: wa_batcher).  Where the pass is ONE launch (wa_rows.hip; it owns the
+// device while it runs) the default is one group of up to 8 - every weight row read once for eight tokens.  Where only the launch
+// sequence is available (a pass is then a chain of short latency-bound launches) groups of 4 run side by side on their own streams:
+// two 4-row passes finish sooner than one 8-row pass after the other (round 2: 8 chunks 488x real time as one group, 589x as two).
 struct wa_batch_groups {
     whisper_context * ctx;
     std::vector<whisper_state *> members;
     std::vector<wa_batcher *> bats;
     wa_batch_groups(whisper_context * c, const std::vector<whisper_state *> & m) : ctx(c), members(m) {
         static const bool off = getenv("WHISPER_AMD_NO_BATCHER") != nullptr;
-        int group = 4;
+        int group = !members.empty() && members[0]->rows_enabled ? WA_MAX_DECODERS : 4;
         if (const char * g = getenv("WHISPER_AMD_BATCH_GROUP")) group = std::max(2, std::min(WA_MAX_DECODERS, atoi(g)));
         for (size_t i0 = 0; i0 < members.size() && !off; i0 += group) {
             const size_t n = std::min((size_t) group, members.size() - i0);
@@ -599,8 +601,8 @@ struct wa_batch_groups {
     }
     ~wa_batch_groups() {
         for (auto * st : members) st->batcher = nullptr;
-        ctx->batch_steps = ctx->batch_rows = 0;
-        for (auto * b : bats) if (b) { long st_ = 0, rw_ = 0; wa_batcher_stats(b, &st_, &rw_); ctx->batch_steps += st_; ctx->batch_rows += rw_; wa_batcher_destroy(b); }
+        ctx->batch_steps = ctx->batch_rows = ctx->batch_one_launch = 0;
+        for (auto * b : bats) if (b) { long st_ = 0, rw_ = 0, ol_ = 0; wa_batcher_stats(b, &st_, &rw_, &ol_); ctx->batch_steps += st_; ctx->batch_rows += rw_; ctx->batch_one_launch += ol_; wa_batcher_destroy(b); }
     }
 };
 
@@ -616,12 +618,9 @@ int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_para
     std::vector<whisper_state *> states;
     std::vector<std::thread> workers;
     std::vector<int> rcs(n_processors, 0);
-    const bool mega0 = ctx->state->mega_enabled;
-    ctx->state->mega_enabled = false;               // several chunks in flight: the launch sequence overlaps better (see whisper_amd_full_batch)
     for (int i = 0; i < n_processors - 1; ++i) {
         whisper_state * st = whisper_init_state(ctx);
-        if (!st) { for (auto * s2 : states) whisper_free_state(s2); ctx->state->mega_enabled = mega0; return -1; }
-        st->mega_enabled = false;
+        if (!st) { for (auto * s2 : states) whisper_free_state(s2); return -1; }
         states.push_back(st);
     }
     std::vector<whisper_state *> members = { ctx->state };
@@ -646,7 +645,6 @@ int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_para
     }
     for (auto & w : workers) w.join();
     }
-    ctx->state->mega_enabled = mega0;
     const int64_t offset_t = (int64_t) params.offset_ms / 10.0;
     for (int i = 0; i < n_processors - 1; ++i) {
         for (auto & r : states[i]->result_all) {
@@ -774,10 +772,8 @@ int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state **
     std::vector<int> rc(n_chunks, 0);
     std::vector<std::thread> th;
     th.reserve(n_chunks);
-    // The one-launch decode step fills the chip by itself and is exclusive per device (wa_decode.cpp), so concurrent chunks
-    // would queue behind each other token by token: with several chunks in flight the launch sequence overlaps better.
-    std::vector<char> mega(n_chunks, 0);
-    if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) { mega[i] = states[i]->mega_enabled; states[i]->mega_enabled = false; }
+    // The one-launch steps own the device while they run (one slot per device, wa_decode.cpp).  Members of a lock-step group do not open
+    // host-overlap windows (wa_full.cpp); a chunk that decodes alone - the last one of its group - takes the slot step by step.
     // ... and where the chunks' loops ask for a plain single-token step at the same time, ONE decoder pass serves a group of them
     {
         wa_batch_groups groups(ctx, std::vector<whisper_state *>(states, states + n_chunks));
@@ -788,7 +784,6 @@ int whisper_amd_full_batch(struct whisper_context * ctx, struct whisper_state **
             });
         for (auto & t : th) t.join();
     }
-    if (n_chunks > 1) for (int i = 0; i < n_chunks; ++i) states[i]->mega_enabled = mega[i];
     for (int r : rc) if (r != 0) return r;
     return 0;
 }

@@ -455,7 +455,7 @@ struct wa_batcher {
     int n_members = 0;                              // threads that may still submit
     struct req { whisper_state * st; int token, pos, n_kv, kv_head; int result; };      // result: 0 pending, 1 logits delivered, -1 not served
     std::vector<req *> waiting;
-    long n_steps = 0, n_rows = 0;
+    long n_steps = 0, n_rows = 0, n_one_launch = 0;       // passes, the token rows they served, passes that were ONE launch (wa_rows.hip)
     // the pass for B rows as a hipGraph (122 launches for ggml-small): captured on first use, replayed while T and the cell count stay
     hipGraphExec_t graph[WA_MAX_DECODERS + 1] = {};
     int graph_T[WA_MAX_DECODERS + 1] = {}; uint32_t graph_kv[WA_MAX_DECODERS + 1] = {};
@@ -479,7 +479,7 @@ void wa_batcher_destroy(wa_batcher * b) {
     if (b->d_rowp) (void) hipFree(b->d_rowp);
     delete b;
 }
-void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows) { if (b) { *steps = b->n_steps; *rows = b->n_rows; } }
+void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows, long * one_launch) { if (b) { *steps = b->n_steps; *rows = b->n_rows; if (one_launch) *one_launch = b->n_one_launch; } }
 
 // all requests of `b->waiting` in one pass; called with b->m held by the thread that completed the set
 static void batcher_run(wa_batcher & b) {
@@ -521,6 +521,7 @@ static void batcher_run(wa_batcher & b) {
                 rr[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, nullptr, run[i]->n_kv, run[i]->kv_head, run[i]->token, run[i]->pos };
             }
             served = rows_step(ctx, bs, B, rr, B, nullptr, T, bs.cross_tpad, s0.kv_self.size, true) == 1;
+            if (served) b.n_one_launch += 1;
         }
         if (!served) {
         (void) hipMemcpyAsync(bs.d_tok, h_tok, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
@@ -851,9 +852,19 @@ extern "C" int whisper_amd_rows_debug(struct whisper_context * ctx, struct whisp
     wa_rows_args a;
     if (!rows_probe_args(*ctx, *st, nullptr, B, toks, n_past, a)) return -2;
     rows_next_seq(*st, a);
+    static float * d_dbg = nullptr;
+    if (const char * e = getenv("WHISPER_AMD_ROWS_TRACE")) {       // stamps of workgroup `e` (tools/rows_trace.py)
+        if (!d_dbg) (void) hipMalloc((void **) &d_dbg, 16384 * 4);
+        (void) hipMemset(d_dbg, 0, 16384 * 4);
+        const int twg = atoi(e);
+        (void) hipMemcpy((int *) d_dbg + 4095, &twg, 4, hipMemcpyHostToDevice);
+        a.dbg = d_dbg;
+    }
     std::lock_guard<std::mutex> lk(mega_slot(ctx->device));
     if (!wa_launch_decode_rows(st->stream, a, std::min(ctx->model.n_cu, 256))) return -4;
+    if (a.dbg) { rows_next_seq(*st, a); (void) wa_launch_decode_rows(st->stream, a, std::min(ctx->model.n_cu, 256)); }      // (the stamps of a warm run)
     if (!WA_HIP_OK(hipStreamSynchronize(st->stream))) return -3;
+    if (a.dbg) { std::vector<unsigned> h(16384); (void) hipMemcpy(h.data(), d_dbg, 16384 * 4, hipMemcpyDeviceToHost); FILE * f = fopen("gpurun_out/rows_trace.bin", "wb"); if (f) { fwrite(h.data(), 4, 16384, f); fclose(f); } else WA_WARN("%s: cannot write gpurun_out/rows_trace.bin\n", __func__); }
     const auto & hp = ctx->model.hp;
     if (granules_out) (void) hipMemcpy(granules_out, st->d_rows_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * B * a.row_gr * 8, hipMemcpyDeviceToHost);
     if (logits_out) (void) hipMemcpy(logits_out, st->d_logits, (size_t) B * hp.n_vocab * 4, hipMemcpyDeviceToHost);

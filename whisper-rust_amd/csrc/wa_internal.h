@@ -124,7 +124,7 @@ struct whisper_context {
     wa_vocab vocab;
     whisper_state * state = nullptr;      // default state (only for the non-_no_state constructors)
     std::string path_model;
-    long batch_steps = 0, batch_rows = 0; // the last whisper_amd_full_batch call: lock-step passes and the token rows they served
+    long batch_steps = 0, batch_rows = 0, batch_one_launch = 0; // the last whisper_amd_full_batch call: lock-step passes, the token rows they served, passes that were one launch
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -320,7 +320,7 @@ struct wa_batcher;
 wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members);      // null: not applicable (quantised model, one chunk)
 void wa_batcher_leave(wa_batcher * b);
 void wa_batcher_destroy(wa_batcher * b);
-void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows);
+void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows, long * one_launch = nullptr);
 bool wa_state_alloc(whisper_context & ctx, whisper_state & st);
 void wa_state_release(whisper_state & st);
 bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells);

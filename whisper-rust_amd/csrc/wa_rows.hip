@@ -34,6 +34,7 @@ __device__ __forceinline__ mb_kargs mb_uniform(mb_kargs p) {
 #define MB_NW 8
 #define MB_NCW 7                  // waves that compute products; wave 7 streams the weights
 #define MB_SPIN_LIMIT 40000u      // polls (~0.5 us each) before a hand-off is declared dead
+#define MB_TRACE_LAYER 5
 #define MB_PAD 64                 // bytes behind every weight row in LDS: consecutive rows start 16 banks apart
 
 enum { E_QKV = 0, E_AO, E_X1, E_QC, E_AO2, E_X2, E_HF, E_X3 };
@@ -54,6 +55,11 @@ __device__ __forceinline__ void mb_barrier_w(int wave) {
     mb_barrier();
 }
 
+// optional timeline (tools/rows_trace.py): 100 MHz wall-clock ticks of one workgroup, 32 stamps per layer
+__device__ __forceinline__ void mb_trace(mb_kargs A, bool who, int slot) {
+    if (A->dbg && who) ((GAS unsigned *) A->dbg)[slot] = (unsigned) wall_clock64();
+}
+
 __device__ __forceinline__ gu64 * mb_edge(mb_kargs A, int layer, int e) {
     return (gu64 *) A->granules + ((size_t) layer * WA_MEGA_EDGES + e) * ((size_t) A->B * A->row_gr);
 }
@@ -64,9 +70,9 @@ __device__ __forceinline__ void mb_sweep(gu64 * g, F idx, mb_ctl & c, int lane, 
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
+        for (int k = 0; k < NPL; ++k) {      // unconditional loads (a lane without a granule reads granule 0): predicated ones are issued one round trip at a time
             const int i = idx(k);
-            if (i >= 0) { const u64 x = gr_load(g + i); v[k] = (unsigned) x; ok &= (unsigned) (x >> 32) == c.seq; }
+            const u64 x = gr_load(g + (i >= 0 ? i : 0)); v[k] = (unsigned) x; ok &= i < 0 || (unsigned) (x >> 32) == c.seq;
         }
         if (__all(ok) || c.dead) return;
         if ((spins & 127u) == 127u) {
@@ -84,15 +90,15 @@ __device__ __forceinline__ void mb_sweep(gu64 * g, F idx, mb_ctl & c, int lane, 
 
 // all 512 threads: `per_row` granules of each of B token rows of `edge` (row b's run starts at b * row_gr), eight per thread and round,
 // handed to store(b, j, value) once valid
-template <typename ST>
+template <int NPL, typename ST>
 __device__ __forceinline__ void mb_gather(mb_ctl & c, gu64 * edge, int B, int per_row, int row_gr, int tid, int lane, ST store, unsigned code) {
     const int total = B * per_row;
-    for (int base = 0; base < total; base += MB_THREADS * 8) {
-        unsigned v[8];
-        mb_sweep<8>(edge, [&](int k) { const int i = base + tid + MB_THREADS * k; if (i >= total) return -1; const int b = i / per_row; return b * row_gr + (i - b * per_row); },
+    for (int base = 0; base < total; base += MB_THREADS * NPL) {
+        unsigned v[NPL];
+        mb_sweep<NPL>(edge, [&](int k) { const int i = base + tid + MB_THREADS * k; if (i >= total) return -1; const int b = i / per_row; return b * row_gr + (i - b * per_row); },
                     c, lane, v, code);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int i = base + tid + MB_THREADS * k; if (i < total) { const int b = i / per_row; store(b, i - b * per_row, v[k]); } }
+        for (int k = 0; k < NPL; ++k) { const int i = base + tid + MB_THREADS * k; if (i < total) { const int b = i / per_row; store(b, i - b * per_row, v[k]); } }
     }
 }
 
@@ -106,20 +112,26 @@ __device__ __forceinline__ double mb_seq_sum(const float (&xv)[NP], int d, bool 
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        for (int j = 0; j < 64; ++j) {
-            const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[k]), j));
-            if (64 * k + j < d) { if (squares) { const float a = x - mean; t += (double) (a * a); } else t += (double) x; }
+#pragma nounroll
+        for (int j0 = 0; j0 < 64; j0 += 8) {
+            double e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[k]), j0 + j));
+                const float a = x - mean;
+                e[j] = 64 * k + j0 + j < d ? (squares ? (double) (a * a) : (double) x) : 0.0;      // (+0.0 leaves an IEEE sum unchanged)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += e[j];
         }
     }
     return t;
 }
 template <int NP>
-__device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_row /* null: embeddings */, const float * lw, const float * lb, int b, int lane,
-                                          wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code) {
+__device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_row /* null: embeddings */, const float * lnp /* LDS: gamma | beta, each d floats in whole KB */, const float * gw_g, const float * gb_g /* global, when non-null */,
+                                          int b, int lane, wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code) {
     const int d = A->d;
-    float xv[NP], gw[NP], gb[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; gw[k] = ((gcf) lw)[ic]; gb[k] = ((gcf) lb)[ic]; }
+    float xv[NP];
     if (edge_row) {
         unsigned v[NP];
         mb_sweep<NP>(edge_row, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
@@ -129,7 +141,7 @@ __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_ro
         const gch te = (gch) A->te + (size_t) A->rows[b].token * d;
         const gcf pe = (gcf) A->pe + (size_t) A->rows[b].pos * d;
 #pragma unroll
-        for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k; xv[k] = i < d ? h2f(te[i]) + pe[i] : 0.0f; }
+        for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; const float e = h2f(te[ic]) + pe[ic]; xv[k] = i < d ? e : 0.0f; }
         if (xres_b) {           // the residual values of the rows this workgroup owns in the d-row products
 #pragma unroll
             for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k; if (i >= row_d && i < row_d + r_d && i < d) xres_b[i - row_d] = xv[k]; }
@@ -158,8 +170,9 @@ __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_ro
         const int i = lane + 64 * k;
         float y = xv[k] - mean;
         y = y * scale;
-        y = y * gw[k];
-        y = y + gb[k];
+        const int ic = i < d ? i : 0;
+        y = y * (gw_g ? ((gcf) gw_g)[ic] : lnp[ic]);
+        y = y + (gb_g ? ((gcf) gb_g)[ic] : lnp[((d + 255) & ~255) + ic]);      // (beta: behind gamma's whole LDS-DMA pieces)
         if (i < d) dst[i] = f2h(y);
     }
 }
@@ -181,6 +194,20 @@ __device__ __forceinline__ void mb_dma_rows(const GAS unsigned char * W, int pit
         gr = gr < n_rows_total ? gr : n_rows_total - 1;
         const GAS unsigned char * src = W + (size_t) gr * pitch + (size_t) (cc < cvalid ? cc : 0) * 16;
         __builtin_amdgcn_global_load_lds((const GAS void *) src, (LAS void *) (slot + (size_t) p * 1024), 16, 0, 0);
+    }
+}
+
+// `n` consecutive floats src[i0 .. i0 + n) (clamped to n_total) -> LDS dst, one dword per lane (no alignment requirement on i0), n <= 64
+__device__ __forceinline__ void mb_dma_f32(const float * src, int i0, int n_total, float * dst, int lane) {
+    const int i = i0 + lane < n_total ? i0 + lane : n_total - 1;
+    __builtin_amdgcn_global_load_lds((const GAS void *) ((gcf) src + i), (LAS void *) dst, 4, 0, 0);
+}
+// a whole F32 vector of n floats (n % 4 == 0, 16-byte aligned) -> LDS
+__device__ __forceinline__ void mb_dma_vec(const float * src, int n, float * dst, int lane) {
+    const int cells = n >> 2;
+    for (int p = 0; p * 64 < cells; ++p) {
+        const int i = p * 64 + lane;
+        __builtin_amdgcn_global_load_lds((const GAS void *) ((gcf) src + 4 * (i < cells ? i : cells - 1)), (LAS void *) ((unsigned char *) dst + (size_t) p * 1024), 16, 0, 0);
     }
 }
 
@@ -254,9 +281,9 @@ __device__ __forceinline__ void mb_dot16(const unsigned char * wrow, const wa_f1
 
 // The product tasks of one weight chunk (Rc rows starting at matrix row `row_base`, in `slot`): task = (group of 64 / LPR weight rows, sub-batch of
 // the token rows), dealt over the computing waves.  epi(values, first token row, end token row, matrix row, lane holds results, bias, scale) - called
-// by every lane; bias / scale of the row are fetched ahead of the product.
+// by every lane; bias / scale of the chunk's rows sit behind the weights in the slot (wave 7 brought them along).
 template <int LPR, int BC, typename EPI>
-__device__ __forceinline__ void mb_products(const unsigned char * slot, int stride, int Rc, int row_base, int N, const float * bias, const float * scale,
+__device__ __forceinline__ void mb_products(const unsigned char * slot, int stride, int Rc, int row_base, int N, const float * bias_l, const float * scale_l,
                                             const wa_f16 * xs, int ldx, int K, int B, int wave, int lane, EPI epi) {
     constexpr int GP = 64 / LPR;
     const int groups = (Rc + GP - 1) / GP, nsub = (B + BC - 1) / BC, per = (B + nsub - 1) / nsub, ntasks = groups * nsub;
@@ -267,7 +294,7 @@ __device__ __forceinline__ void mb_products(const unsigned char * slot, int stri
         const bool valid = ri < Rc && row_base + ri < N;
         const unsigned char * wrow = slot + (size_t) (ri < Rc ? ri : Rc - 1) * stride + u * (LPR == 8 ? 8 : 4);
         const bool has = valid && u == 0;
-        const float bv = has && bias ? ((gcf) bias)[row_base + ri] : 0.0f, sv = has && scale ? ((gcf) scale)[row_base + ri] : 1.0f;
+        const float bv = bias_l[ri < 64 ? ri : 63], sv = scale_l ? scale_l[ri < 64 ? ri : 63] : 1.0f;
         float res[BC];
         if constexpr (LPR == 8) mb_dot8<BC>(wrow, xs + 4 * u, ldx, b0, B, K >> 5, res);
         else                    mb_dot16<BC>(wrow, xs + 2 * u, ldx, b0, B, K >> 5, res);
@@ -336,6 +363,25 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
     const gch kp = (gch) A->rows[b].kv_k + (size_t) l * A->kv_layer_stride + h * 64;
     const gch vp = (gch) A->rows[b].kv_v + (size_t) l * A->kv_layer_stride + h * 64;
     const GAS int8_t * mrow = (const GAS int8_t *) A->rows[b].mask;
+    // requested before the query is waited for: the keys of the first 512 cells (4 per 4-lane group) and the values of the first four P V steps
+    const int a_ = tid & 3, kslot_ = tid >> 2;
+    u32x4 ka0[4], kb0[4];
+    wa_f16 vv0[4][4];
+    {
+        const int nst = (n_kv & ~31) >> 5;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int cc = p * (MB_THREADS / 4) + kslot_; cc = cc < n_kv ? cc : n_kv - 1;
+            ka0[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 8 * a_); kb0[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 32 + 8 * a_);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sidx = q < nst ? q : (nst > 0 ? nst - 1 : 0);
+                vv0[q][i] = *(const GAS wa_f16 *) (vp + (size_t) (sidx * 32 + wave * 4 + i) * d + lane);
+            }
+    }
     if (wave < B) {         // wave j: k | v of row j (two runs of 32 packed granules), and the query when j is this row
         const bool same = A->rows[wave].kv_k == A->rows[b].kv_k;
         if (same) {
@@ -370,7 +416,8 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 int cc = c0 + p * (MB_THREADS / 4) + kslot; cc = cc < n_kv ? cc : n_kv - 1;
-                ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 8 * a); kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 32 + 8 * a);
+                if (c0 == 0) { ka[p] = ka0[p]; kb[p] = kb0[p]; }
+                else { ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 8 * a); kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 32 + 8 * a); }
                 mk[p] = mrow ? mrow[cc] : (int8_t) 0;
             }
 #pragma unroll
@@ -455,7 +502,7 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int sidx = s0 + q < nsteps ? s0 + q : nsteps - 1, cc = sidx * 32 + r0 + i;
-                    vv[q][i] = *(const GAS wa_f16 *) (vp + (size_t) cc * d + lane);
+                    if (s0 == 0) vv[q][i] = vv0[q][i]; else vv[q][i] = *(const GAS wa_f16 *) (vp + (size_t) cc * d + lane);
                     const int j = new_of(cc);       // (wave-uniform)
                     if (j >= 0) vv[q][i] = vnew[j * 64 + lane];
                 }
@@ -484,9 +531,27 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
 #define MB_CGR_SUM 8
 #define MB_CGR_PART 64
 
-__device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int w, int tid) {
+struct mb_cross_regs { u32x4 ka[3], kb[3]; unsigned short vv[MB_CSTEPS]; };
+// own keys (24 registers) and own chain elements of quarter w of (row b, head h): unconditional, clamped loads - all in flight together
+__device__ __forceinline__ void mb_cross_load(mb_kargs A, int l, int b, int h, int w, int tid, mb_cross_regs & R) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = A->T, tpad = A->cross_tpad, a = tid & 3, ks = tid >> 2, nsteps = (T & ~31) >> 5;
+    const gch kp = (gch) A->rows[b].cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
+    const gch vp = (gch) A->rows[b].cross_v + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int o = p * 128 + ks, c0 = 32 * (o >> 3) + 8 * w + (o & 7), cc = c0 < T ? c0 : T - 1;
+        R.ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 8 * a); R.kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 32 + 8 * a);
+    }
+#pragma unroll
+    for (int s = 0; s < MB_CSTEPS; ++s) { const int sc_ = s < nsteps ? s : (nsteps > 0 ? nsteps - 1 : 0); R.vv[s] = *(const GAS unsigned short *) (vp + (size_t) (32 * sc_ + 8 * w + wave) * 64 + lane); }
+}
+
+__device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int w, int tid, bool tw, const mb_cross_regs & R) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned seq = c.seq;
+#define MB_TC(k) mb_trace(A, tw, l * 32 + 16 + (k))
+    MB_TC(0);
     float  * part  = (float *) area;                                  // [32][64]
     wa_f16 * vleft = (wa_f16 *) (area + 8192);                        // [32][64]
     float  * sc    = (float *) (area + 8192 + 4096);                  // [384]
@@ -501,18 +566,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
     const int a = tid & 3, ks = tid >> 2;
     const int np = T & ~31, nsteps = np >> 5, nl = T - np, n8 = T & ~7, ng = n8 >> 3;
     gu64 * X = (gu64 *) A->cross_gr + (((size_t) l * A->B + b) * H + h) * WA_ROWS_CGR;
-    const gch kp = (gch) A->rows[b].cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
     const gch vp = (gch) A->rows[b].cross_v + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
-    // own keys, own chain elements, leftover V rows
-    u32x4 ka[3], kb[3];
-    unsigned short vv[MB_CSTEPS];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int o = p * 128 + ks, cc = 32 * (o >> 3) + 8 * w + (o & 7);
-        if (cc < T) { ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 8 * a); kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 32 + 8 * a); }
-    }
-#pragma unroll
-    for (int s = 0; s < MB_CSTEPS; ++s) if (s < nsteps) vv[s] = *(const GAS unsigned short *) (vp + (size_t) (32 * s + 8 * w + wave) * 64 + lane);
     if (w == 0 && tid < 256) {
         const int row = tid >> 3;
         if (row < nl) *(u32x4 *) (vleft + (size_t) tid * 8) = *(const GAS u32x4 *) (vp + (size_t) (np + row) * 64 + (tid & 7) * 8);
@@ -521,8 +575,10 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         unsigned v[1];
         mb_sweep<1>(mb_edge(A, l, E_QC) + (size_t) b * A->row_gr, [&](int) { return lane < 32 ? h * 32 + lane : -1; }, c, lane, v, 2000u + l);
         if (lane < 32) ((unsigned *) qs)[lane] = v[0];
+        MB_TC(1);
     }
     mb_barrier();
+    MB_TC(2);
     // ---- scores of the own cells (local index o = 8 s + r  <->  cell 32 s + 8 w + r) ----
     float lmax = -INFINITY;
     {
@@ -532,12 +588,13 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int o = p * 128 + ks, cc = 32 * (o >> 3) + 8 * w + (o & 7);
-            const float r = mb_score(ka[p], kb[p], qa, qb, kq_scale);
+            const float r = mb_score(R.ka[p], R.kb[p], qa, qb, kq_scale);
             if (cc < T) { if (a == 0) sc[o] = r; lmax = fmaxf(lmax, r); }
         }
     }
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
+    MB_TC(3);
     mb_barrier();
     if (wave == 0) {        // (1) maxima of the four quarters
         float m = red[0];
@@ -551,6 +608,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         if (lane == 0) bc[0] = g;
     }
     mb_barrier();
+    MB_TC(4);
     const float mx = bc[0];
     // ---- exp, group sums (8-lane tree = ops.cpp's), F64 partial sum: thread = one own cell ----
     {
@@ -568,6 +626,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         ps = wave_sum_d(ps);
         if (lane == 0) redd[wave] = ps;
     }
+    MB_TC(5);
     mb_barrier();
     if (wave == 0) {        // (2) partial sums -> total, certified
         const double ps = ((redd[0] + redd[1]) + (redd[2] + redd[3])) + ((redd[4] + redd[5]) + (redd[6] + redd[7]));
@@ -587,6 +646,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         if (lane == 0) bc[1] = ilo;
     }
     mb_barrier();
+    MB_TC(6);
     const float inv = bc[1];
     if (tid < 8 * MB_CSTEPS) {
         const int cc = 32 * (tid >> 3) + 8 * w + (tid & 7);
@@ -597,6 +657,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         }
     }
     mb_barrier();
+    MB_TC(7);
     // ---- P V: wave = own chain (cells 32 s + 8 w + wave), lane = d_head index ----
     {
         float acc = 0.0f;
@@ -604,10 +665,11 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
 #pragma unroll
         for (int k = 0; k < MB_CSTEPS / 8; ++k) pw[k] = *(const half8 *) (p16 + wave * MB_CSTEPS + 8 * k);
 #pragma unroll
-        for (int s = 0; s < MB_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(vv[s]), (float) pw[s >> 3][s & 7], acc);
+        for (int s = 0; s < MB_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(R.vv[s]), (float) pw[s >> 3][s & 7], acc);
         if (w == 0) part[wave * 64 + lane] = acc;
         else gr_store(X + MB_CGR_PART + (w - 1) * 576 + wave * 64 + lane, seq, __float_as_uint(acc));
     }
+    MB_TC(8);
     if (w == 0) {           // (3) gather the other three quarters' chain sums and leftover probabilities, finish the head
         if (wave >= 1 && wave <= 6) {
             const int ww = (wave - 1) >> 1, half = (wave - 1) & 1;
@@ -619,7 +681,9 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
             if (half == 0 && lane < 8) { const int cc = 8 * (ww + 1) + lane; if (cc < nl) pleft[cc] = (wa_f16) v[4]; }
         }
         mb_barrier();
+        MB_TC(9);
         mb_attn_finish(part, vleft, pleft, nl, mb_edge(A, l, E_AO2) + (size_t) b * A->row_gr, h, seq, tid);
+        MB_TC(10);
     }
     mb_barrier();
 }
@@ -641,9 +705,9 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
         const int j = it / nbat, bt = it - j * nbat, row = grp(j) * 8 + (lane >> 3);
         const gch wrow = (gch) A->te + (size_t) (row < n_vocab ? row : 0) * d + 4 * u;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) {
+        for (int k = 0; k < 24; ++k) {       // (unconditional: every load of a piece in flight together)
             const int s = bt * 24 + k;
-            if (s < ns) { const u32x2 t = *(const GAS u32x2 *) (wrow + (size_t) s * 32); buf[2 * k] = t.x; buf[2 * k + 1] = t.y; }
+            const u32x2 t = *(const GAS u32x2 *) (wrow + (size_t) (s < ns ? s : ns - 1) * 32); buf[2 * k] = t.x; buf[2 * k + 1] = t.y;
         }
     };
     float acc[BT][4];
@@ -713,11 +777,14 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     const int d = A->d, L = A->n_layer, B = A->B, H = A->n_head, d4 = 4 * d, RG = A->row_gr;
     const mb_layers Ly = (mb_layers) A->layers;
 
-    // LDS: xres [8][8] f32 | xinB [B][d] f16 (LayerNorm outputs) | area: xin [B][4d] f16 (gathered inputs) / attention scratch | slot 0 | slot 1
+    // LDS: xres [8][8] f32 | lnp: gamma [d] | beta [d] f32 of the next LayerNorm | xinB [B][d] f16 (LayerNorm outputs) | area: xin [B][4d] f16 (gathered
+    // inputs) / attention scratch | slot 0 | slot 1 (weight rows, then - in the last KB - the rows' bias and scale)
     float  * xres = (float *) smem;
-    wa_f16 * xinB = (wa_f16 *) (smem + 256);
+    float  * lnp  = (float *) (smem + 256);
+    const size_t lnp_bytes = 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023);      // (an LDS-DMA instruction writes a whole KB: each vector ends on one)
+    wa_f16 * xinB = (wa_f16 *) (smem + 256 + lnp_bytes);
     const size_t xinB_bytes = ((size_t) B * d * 2 + 255) & ~(size_t) 255;
-    unsigned char * area = smem + 256 + xinB_bytes;
+    unsigned char * area = smem + 256 + lnp_bytes + xinB_bytes;
     wa_f16 * xin = (wa_f16 *) area;
     size_t area_bytes = (size_t) B * d4 * 2;
     if (area_bytes < MB_ATT_BYTES) area_bytes = MB_ATT_BYTES;
@@ -740,7 +807,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         else if (p == 4) { ph.W = Y.fc1_w; ph.bias = Y.fc1_b; ph.N = d4; ph.K = d; ph.r = r_ff; }
         else             { ph.W = Y.fc2_w; ph.bias = Y.fc2_b; ph.N = d; ph.K = d4; ph.r = r_d; }
         const int gp = p == 5 ? 4 : 8, stride = 2 * ph.K + MB_PAD;
-        int rc = (slot_bytes / stride) / gp * gp;
+        int rc = ((slot_bytes - 1024) / stride) / gp * gp;
         const int rmax = (ph.r + gp - 1) / gp * gp;
         ph.rc = rc > rmax ? rmax : rc;
         ph.nck = (ph.r + ph.rc - 1) / ph.rc;
@@ -752,7 +819,19 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         const int row0 = wg * ph.r + ck * ph.rc;
         if (row0 >= ph.N) return;
         const int R = min(ph.rc, ph.r - ck * ph.rc);
-        mb_dma_rows((const GAS unsigned char *) ph.W, 2 * ph.K, row0, R, ph.N, slot0 + (size_t) par * slot_bytes, lane);
+        unsigned char * slot = slot0 + (size_t) par * slot_bytes;
+        mb_dma_rows((const GAS unsigned char *) ph.W, 2 * ph.K, row0, R, ph.N, slot, lane);
+        mb_dma_f32(ph.bias, row0, ph.N, (float *) (slot + slot_bytes - 512), lane);
+        if (ph.scale) mb_dma_f32(ph.scale, row0, ph.N, (float *) (slot + slot_bytes - 256), lane);
+    };
+    // wave 7: the parameters of the LayerNorm that follows the product phase p of layer l
+    auto request_ln = [&](int l, int p) {
+        const float * w, * b_;
+        if (p == 0)      { w = Ly[l].ln2_w; b_ = Ly[l].ln2_b; }
+        else if (p == 2) { w = Ly[l].ln3_w; b_ = Ly[l].ln3_b; }
+        else if (l + 1 < L) { w = Ly[l + 1].ln1_w; b_ = Ly[l + 1].ln1_b; }
+        else             { w = A->lnf_w; b_ = A->lnf_b; }
+        mb_dma_vec(w, d, lnp, lane); mb_dma_vec(b_, d, lnp + ((d + 255) & ~255), lane);
     };
     int par = 0;                 // parity of the chunk the NEXT product phase reads
     // One product phase: `front` has filled the operand rows in LDS; per chunk: barrier (weights landed, operand visible, previous chunk's
@@ -765,6 +844,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                 int nl_ = l, np_ = p, nc_ = ck + 1;
                 if (nc_ >= ph.nck) { nc_ = 0; np_ = p + 1; if (np_ >= 6) { np_ = 0; nl_ = l + 1; } }
                 if (nl_ < L) request(nl_, np_, nc_, par ^ 1);
+                if (ck == 0 && (p == 0 || p == 2 || p == 4)) request_ln(l, p);      // (the LayerNorm before this phase has been through: its parameters may go)
             } else {
                 const int Rc = min(ph.rc, ph.r - ck * ph.rc);
                 tasks(ph, slot0 + (size_t) par * slot_bytes, wg * ph.r + ck * ph.rc, Rc);
@@ -774,22 +854,27 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     };
 
     if (wave == MB_NW - 1 && L > 0) request(0, 0, 0, 0);
+    const int twg = A->dbg ? ((const GAS int *) A->dbg)[4095] : 0;          // (trace: the workgroup that stamps)
+    const bool tw = wg == twg && tid == 0;
+#define MB_T(k) do { mb_trace(A, tw, l * 32 + (k)); mb_trace(A, tid == 0 && l == MB_TRACE_LAYER, 8192 + wg * 16 + (k)); } while (0)      /* every workgroup at ONE layer */
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
+        MB_T(0);
         // ---------------- P1: LayerNorm + q|k|v ----------------
-        if (wave < B) mb_ln_row<NP>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, Y.ln1_w, Y.ln1_b, wave, lane, xinB + (size_t) wave * d,
-                                    xres + wave * 8, row_d, r_d, 100u + l);
+        if (wave < B) mb_ln_row<NP>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, l == 0 ? Y.ln1_w : nullptr, l == 0 ? Y.ln1_b : nullptr,
+                                    wave, lane, xinB + (size_t) wave * d, xres + wave * 8, row_d, r_d, 100u + l);
+        MB_T(1);
         run_phase(l, 0, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
             gu64 * eq = mb_edge(A, l, E_QKV);
-            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, ph.scale, xinB, d, ph.K, B, wave, lane,
+            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), (const float *) (slot + slot_bytes - 256), xinB, d, ph.K, B, wave, lane,
                               [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float scale) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const int b = b0 + j;
+                    const int b = __builtin_amdgcn_readfirstlane(b0 + j < b1 ? b0 + j : b1 - 1);      // (wave-uniform: the row record comes by scalar loads)
                     float v = res[j] + bias;
                     v = v * scale;
                     const unsigned pk = mb_pack_h2((unsigned) f2h(v));
-                    if (has && b < b1 && (lane & 15) == 0) {
+                    if (has && b0 + j < b1 && (lane & 15) == 0) {
                         gr_store(eq + (size_t) b * RG + (n >> 1), seq, pk);
                         if (n >= d) {       // new key / value also go to the row's KV cell for later tokens
                             GAS wa_f16 * cell = (n < 2 * d ? (GAS wa_f16 *) A->rows[b].kv_k + (n - d) : (GAS wa_f16 *) A->rows[b].kv_v + (n - 2 * d)) +
@@ -800,14 +885,16 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                 }
             });
         });
+        MB_T(2);
         // ---------------- P2: self-attention ----------------
         for (int u = wg; u < B * H; u += nwg) mb_unit_self(A, c, area, l, u / H, u % H, tid);
+        MB_T(3);
         // ---------------- P3: out-projection + residual ----------------
-        mb_gather(c, mb_edge(A, l, E_AO), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 200u + l);
+        mb_gather<8>(c, mb_edge(A, l, E_AO), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 200u + l);
         auto resid_tasks = [&](int e_out) {
             return [&, e_out](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
                 gu64 * ex = mb_edge(A, l, e_out);
-                mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xin, d4, ph.K, B, wave, lane,
+                mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xin, d4, ph.K, B, wave, lane,
                                   [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
@@ -822,12 +909,15 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                 });
             };
         };
+        MB_T(4);
         run_phase(l, 1, resid_tasks(E_X1));
+        MB_T(5);
         // ---------------- P4: LayerNorm + cross query ----------------
-        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X1) + (size_t) wave * RG, Y.ln2_w, Y.ln2_b, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 300u + l);
+        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X1) + (size_t) wave * RG, lnp, nullptr, nullptr, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 300u + l);
+        MB_T(6);
         run_phase(l, 2, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
             gu64 * eq = mb_edge(A, l, E_QC);
-            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xinB, d, ph.K, B, wave, lane,
+            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xinB, d, ph.K, B, wave, lane,
                               [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -838,17 +928,27 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                 }
             });
         });
+        MB_T(7);
         // ---------------- P5: cross-attention ----------------
-        for (int u = wg; u < B * H * 4; u += nwg) { const int bh = u >> 2; mb_unit_cross(A, c, area, l, bh / H, bh % H, u & 3, tid); }
+        for (int u = wg; u < B * H * 4; u += nwg) {
+            const int bh = u >> 2;
+            mb_cross_regs CR;       // (asked for here: earlier - across the cross-query products - the 72 registers cost those products 2 us and won 0.8)
+            mb_cross_load(A, l, bh / H, bh % H, u & 3, tid, CR);
+            mb_unit_cross(A, c, area, l, bh / H, bh % H, u & 3, tid, tw, CR);
+        }
+        MB_T(8);
         // ---------------- P6: out-projection + residual ----------------
-        mb_gather(c, mb_edge(A, l, E_AO2), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 400u + l);
+        mb_gather<8>(c, mb_edge(A, l, E_AO2), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 400u + l);
+        MB_T(9);
         run_phase(l, 3, resid_tasks(E_X2));
+        MB_T(10);
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
-        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X2) + (size_t) wave * RG, Y.ln3_w, Y.ln3_b, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 500u + l);
+        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X2) + (size_t) wave * RG, lnp, nullptr, nullptr, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 500u + l);
+        MB_T(11);
         run_phase(l, 4, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
             gu64 * eh = mb_edge(A, l, E_HF);
             const GAS wa_f16 * gelu = (const GAS wa_f16 *) A->gelu;
-            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xinB, d, ph.K, B, wave, lane,
+            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xinB, d, ph.K, B, wave, lane,
                               [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
                 float tv[3];                                           // wa_gelu (vec.h:571-585) through the F16 table: the look-ups of the token rows together
 #pragma unroll
@@ -864,11 +964,13 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                 }
             });
         });
+        MB_T(12);
         // ---------------- P8: FC2 + residual ----------------
-        mb_gather(c, mb_edge(A, l, E_HF), B, d4 >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 600u + l);
+        mb_gather<16>(c, mb_edge(A, l, E_HF), B, d4 >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 600u + l);
+        MB_T(13);
         run_phase(l, 5, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
             gu64 * ex = mb_edge(A, l, E_X3);
-            mb_products<16, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, ph.bias, nullptr, xin, d4, ph.K, B, wave, lane,
+            mb_products<16, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xin, d4, ph.K, B, wave, lane,
                                [&](float (&res)[2], int b0, int b1, int n, bool has, float bias, float) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -883,15 +985,17 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
             });
         });
     }
+    { const int l = L; MB_T(0); }
     // ---------------- final LayerNorm + logits (of the token rows that want them) ----------------
     const int n_out = A->n_out;
     if (wave < n_out) {
         const int br = A->out_row[wave];
-        mb_ln_row<NP>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, A->lnf_w, A->lnf_b, br, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 3000u);
+        mb_ln_row<NP>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, lnp, L > 0 ? nullptr : A->lnf_w, L > 0 ? nullptr : A->lnf_b, br, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 3000u);
     }
     mb_barrier();
     if (n_out <= 2) mb_logits<2>(A, xinB, n_out, lane, wave); else if (n_out <= 4) mb_logits<4>(A, xinB, n_out, lane, wave);
     else if (n_out <= 5) mb_logits<5>(A, xinB, n_out, lane, wave); else mb_logits<8>(A, xinB, n_out, lane, wave);
+    { const int l = L; MB_T(1); }
     if (wg == 0 && tid == 0) ((GAS unsigned *) A->status)[1] = seq;       // this launch ran (the host accepts a step only with its own number here)
 }
 
@@ -906,20 +1010,20 @@ size_t wa_rows_lds_bytes(int d, int B, int n_wg, int * slot_bytes) {
     size_t area = (size_t) B * 4 * d * 2;
     if (area < MB_ATT_BYTES) area = MB_ATT_BYTES;
     area = (area + 255) & ~(size_t) 255;
-    const size_t fixed = 256 + xinB_bytes + area;
+    const size_t fixed = 256 + 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023) + xinB_bytes + area;
     auto rpw = [&](int N) { const int r = (N + n_wg - 1) / n_wg; return (r + 1) & ~1; };
     if (rpw(d) > 8) return 0;                       // (xres holds 8 residual values per token row)
     // a slot holds at least one task group of every phase; the whole chunk of a phase when there is room (fewer barriers)
-    const size_t need_min = std::max((size_t) 8 * (2 * d + MB_PAD), (size_t) 4 * (8 * d + MB_PAD));
+    const size_t need_min = std::max((size_t) 8 * (2 * d + MB_PAD), (size_t) 4 * (8 * d + MB_PAD)) + 1024;      // (+ the KB of bias / scale behind the rows)
     size_t want = 0;
     want = std::max(want, (size_t) ((rpw(3 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
     want = std::max(want, (size_t) ((rpw(4 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
     want = std::max(want, (size_t) ((rpw(d) + 3) / 4 * 4) * (8 * d + MB_PAD));
+    want = ((want + 1023) & ~(size_t) 1023) + 1024;
     const size_t total_max = 160 * 1024;
     if (fixed + 2 * (need_min + 1024) > total_max) return 0;
-    size_t slot = std::min(want, (total_max - fixed) / 2 - 1024);
-    slot = (slot + 1023) & ~(size_t) 1023;          // whole LDS-DMA pieces
-    if (fixed + 2 * slot > total_max) slot -= 1024;
+    size_t slot = std::min(want, (total_max - fixed) / 2);
+    slot &= ~(size_t) 1023;                         // whole LDS-DMA pieces
     if (slot < need_min) return 0;
     if (slot_bytes) *slot_bytes = (int) slot;
     return fixed + 2 * slot;

@@ -208,6 +208,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     proto("whisper_log_set", None, LOG_CB, P)
     if hasattr(lib, "whisper_amd_full_batch"):
         proto("whisper_amd_full_batch", I, P, C.POINTER(C.c_void_p), I, whisper_full_params, C.POINTER(C.c_void_p), C.POINTER(C.c_int))
+    if hasattr(lib, "whisper_amd_rows_stats"):
+        proto("whisper_amd_rows_stats", None, P, C.POINTER(C.c_long))
+        proto("whisper_amd_rows_enabled", I, P)
+        proto("whisper_amd_batch_one_launch", C.c_long, P)
     _LIBS[path] = lib
     return lib
 
@@ -403,6 +407,12 @@ class WhisperState:
         if r < 0:
             raise WhisperError("GenericError", r)
         return r, np.array(probs[:], dtype=np.float32)
+
+    def rows_stats(self) -> tuple:
+        """Extension: (decoder passes of several token rows served by the one-launch form, passes sent back to the launch sequence)."""
+        out = (C.c_long * 2)()
+        self.lib.whisper_amd_rows_stats(self.ptr, out)
+        return int(out[0]), int(out[1])
 
     def n_len(self) -> int:
         return self.lib.whisper_n_len_from_state(self.ptr)
