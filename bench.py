@@ -75,6 +75,20 @@ class Hip:
         self.check(self.lib.hipDeviceSynchronize(), "hipDeviceSynchronize")
 
 
+class StubEngine:
+    """Stands in for the HIP library in the CPU rehearsal of the N > 1 control flow (tests/test_bench_dist.py, --stub): the model image is
+    only check-summed, a step sleeps a few ms per chunk and "decodes" 7 tokens per chunk.  Everything around it - rank / chunk partition,
+    the weight broadcast, barriers, the MAX / SUM reductions, the config-3 object - is bench.py's real code."""
+
+    def __init__(self, image, rank):
+        self.sum = int(np.asarray(image, dtype=np.uint8).astype(np.uint64).sum())
+        self.rank = rank
+
+    def step(self, chunk_ids):
+        time.sleep(0.002 * len(chunk_ids) * (1 + self.rank))
+        return 7 * len(chunk_ids)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,12 +97,14 @@ def main():
     ap.add_argument("--model", default="small", choices=list(wsynth.SHAPES))
     ap.add_argument("--chunks-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-concurrent", action="store_true", help="skip the 4-concurrent-chunks extra (threads + graph capture upset rocprofv3)")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the 8-concurrent-chunks extra (threads upset rocprofv3)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 4 (medium, beam 5 + DTW) and 5 (large-v3 Q5_0) - they write 1.5 + 3.1 GB of synthetic models")
     ap.add_argument("--flash-attn", type=int, default=0, help="0 = reference-order path, bit-identical to whisper.cpp CPU (default: what whisper-rs gets, "
                     "src/whisper_ctx.rs:490, and the path that meets north_star's parity bar); 1 = F16-MFMA tolerance path as the headline")
     ap.add_argument("--no-second-path", action="store_true", help="skip timing the other flash_attn setting in the same run")
     ap.add_argument("--json-out", default=None, help="also write the JSON line to this file (profiler runs mix their log into stdout)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on a 1-GPU box)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path on a 1-GPU box / on CPU)")
+    ap.add_argument("--stub", action="store_true", help="CPU rehearsal of the N > 1 control flow: no HIP library, a stub step (tests/test_bench_dist.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,92 +114,118 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     dist = None
+    torch = None
     if world > 1:
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
-        n_dev = torch.cuda.device_count()
+        n_dev = 0 if args.stub else torch.cuda.device_count()
         local_dev = local_rank % max(1, n_dev)          # rehearsal: several ranks may share one card
-        if world > max(1, n_dev):
-            # ranks sharing a card: the one-launch decode step wants every CU for itself (its workgroups wait for each other, two of
+        if world > max(1, n_dev) and not args.stub:
+            # ranks sharing a card: the one-launch decode steps want every CU for themselves (their workgroups wait for each other, two of
             # them interleaved could starve) - the rehearsal runs the launch sequence; one rank per GPU (the real run) is unaffected
             os.environ["WHISPER_AMD_NO_MEGA"] = "1"
-        torch.cuda.set_device(local_dev)
+        if not args.stub:
+            torch.cuda.set_device(local_dev)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
         else:
             dist.init_process_group(args.dist_backend)
     else:
         local_dev = local_rank
+    cdev = "cuda" if (dist is not None and args.dist_backend == "nccl") else "cpu"
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per concurrent chunk stream
-    hip = Hip()
-    hip.set_device(local_dev)
-    lib = W.load_library()          # fails loudly if the HIP library is missing
-    W.set_log_callback(lib, lambda lvl, txt: sys.stderr.write(txt) if lvl >= 3 else None)
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=cdev)
+        dist.all_reduce(t)
+        return int(t.item())
+
+    hip = lib = None
+    if not args.stub:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # one hardware queue per concurrent chunk stream
+        hip = Hip()
+        hip.set_device(local_dev)
+        lib = W.load_library()          # fails loudly if the HIP library is missing
+        W.set_log_callback(lib, lambda lvl, txt: sys.stderr.write(txt) if lvl >= 3 else None)
     shape = wsynth.SHAPES[args.model]
 
-    # ---- weights: rank 0 owns the file image; other ranks receive it over RCCL/xGMI (no per-rank disk read)
+    # ---- weights: rank 0 owns the file; the other ranks receive its image over RCCL / xGMI straight into the buffer the loader parses
+    #      (no per-rank disk read, no intermediate copies: the library copies nothing beyond the init call, whisper.cpp:3684-3719)
+    mp = None
+    image = None
     if rank == 0:
-        mp = wsynth.model_path(args.model)
+        mp = wsynth.model_path("s64" if args.stub else args.model)
     if world > 1:
-        import torch
-        cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
-        if rank == 0:
-            img = torch.from_numpy(np.fromfile(mp, dtype=np.uint8)).to(cdev)
-            n = torch.tensor([img.numel()], dtype=torch.int64, device=cdev)
-        else:
-            n = torch.zeros(1, dtype=torch.int64, device=cdev)
+        n = torch.tensor([os.path.getsize(mp) if rank == 0 else 0], dtype=torch.int64, device=cdev)
         dist.broadcast(n, 0)
-        if rank != 0:
-            img = torch.empty(int(n.item()), dtype=torch.uint8, device=cdev)
-        dist.broadcast(img, 0)
-        buf = img.cpu().numpy().tobytes()
-        ctx = W.WhisperContext.new_from_buffer_with_params(
-            buf, W.WhisperContextParameters(lib, gpu_device=local_dev, flash_attn=bool(args.flash_attn)), lib=lib)
-        del img, buf
-    else:
-        ctx = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(lib, gpu_device=local_dev, flash_attn=bool(args.flash_attn)), lib=lib)
-
+        image = np.fromfile(mp, dtype=np.uint8) if rank == 0 else np.empty(int(n.item()), dtype=np.uint8)
+        host_t = torch.from_numpy(image)            # shares the numpy buffer
+        if cdev == "cuda":
+            dev_t = host_t.to("cuda") if rank == 0 else torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
+            dist.broadcast(dev_t, 0)
+            if rank != 0:
+                host_t.copy_(dev_t)                 # one D2H copy into the buffer init_from_buffer reads
+            del dev_t
+        else:
+            dist.broadcast(host_t, 0)               # in place
     n_chunks = args.chunks_per_gpu
-    states = [ctx.create_state() for _ in range(n_chunks)]
-    pcm_host = [wsynth.synth_audio(480000, rank * n_chunks + i) for i in range(n_chunks)]
-    pcm_dev = [hip.to_device(p) for p in pcm_host]
-    fp = W.FullParams(lib, best_of=1, temperature_inc=0.0, language="en", no_context=True)
+    # chunk ids of this rank: the block partition of [0, world * n_chunks) (chunk_dp.shard_chunks) - the id seeds the chunk's audio
+    import chunk_dp
+    my_ids = list(chunk_dp.shard_chunks(world * n_chunks, rank, world))
+    if args.stub:
+        eng = StubEngine(image if image is not None else np.fromfile(mp, dtype=np.uint8), rank)
+        ctx = states = pcm_host = pcm_dev = fp = None
 
-    def step():
-        if n_chunks == 1:
-            states[0].full(fp, (pcm_dev[0], 480000))
-        else:       # independent chunks of this rank run concurrently, one stream + host thread each
-            W.full_batch(ctx, states, fp, [(dp, 480000) for dp in pcm_dev])
-        return sum(st.full_n_tokens(i) for st in states for i in range(st.full_n_segments()))
+        def step():
+            return eng.step(my_ids)
+    else:
+        cparams = W.WhisperContextParameters(lib, gpu_device=local_dev, flash_attn=bool(args.flash_attn))
+        if world > 1 and rank != 0:
+            ctx = W.WhisperContext.new_from_buffer_with_params(image, cparams, lib=lib)
+        else:
+            ctx = W.WhisperContext.new_with_params(mp, cparams, lib=lib)
+        image = None
+        states = [ctx.create_state() for _ in my_ids]
+        pcm_host = [wsynth.synth_audio(480000, i) for i in my_ids]
+        pcm_dev = [hip.to_device(p) for p in pcm_host]
+        fp = W.FullParams(lib, best_of=1, temperature_inc=0.0, language="en", no_context=True)
+
+        def step():
+            if n_chunks == 1:
+                states[0].full(fp, (pcm_dev[0], 480000))
+            else:       # independent chunks of this rank: one host thread each, their single-token steps decoded in lock step
+                W.full_batch(ctx, states, fp, [(dp, 480000) for dp in pcm_dev])
+            return sum(st.full_n_tokens(i) for st in states for i in range(st.full_n_segments()))
+
+    def sync():
+        if hip is not None:
+            hip.sync()
 
     for _ in range(args.warmup):
         step()
-    hip.sync()
+    sync()
     barrier()
     t0 = time.perf_counter()
     ntok = 0
     for _ in range(args.steps):
         ntok = step()
-    hip.sync()
+    sync()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        cdev = "cuda" if args.dist_backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tk = torch.tensor([ntok], dtype=torch.int64, device=cdev)
-        dist.all_reduce(tk)
-        ntok_all = int(tk.item())
-    else:
-        ntok_all = ntok
+    dt = reduce_max(time.perf_counter() - t0)
+    ntok_all = reduce_sum(ntok)
 
     audio_s = 30.0 * n_chunks * world * args.steps
     rtf = audio_s / dt
@@ -195,7 +237,47 @@ def main():
         "config": {"workload": "ggml-%s-shaped synthetic F16 model, greedy best_of=1 temperature_inc=0, %d x 30 s 16 kHz f32 chunk per GPU, PCM resident in HBM"
                                % (args.model, n_chunks),
                    "tokens_decoded_per_step": ntok_all, "flash_attn": bool(args.flash_attn), "parallelism": "chunk-dp%d" % world},
+        "tokens_per_s": round(ntok_all * args.steps / dt, 1),
     }
+
+    # ---- BASELINE config 3's shape on every N: 8 chunks per GPU (64 over 8 GPUs), each rank's chunks through its lock-step batcher;
+    #      same protocol (barrier, MAX over ranks); reported beside the headline, which stays one chunk per GPU unless --chunks-per-gpu says so
+    if (world > 1 or args.stub) and n_chunks != 8:
+        c3_ids = list(chunk_dp.shard_chunks(world * 8, rank, world))
+        if args.stub:
+            def c3_step():
+                return eng.step(c3_ids)
+        else:
+            c3_states = [ctx.create_state() for _ in c3_ids]
+            c3_pcm = [hip.to_device(wsynth.synth_audio(480000, 1000 + i)) for i in c3_ids]
+
+            def c3_step():
+                W.full_batch(ctx, c3_states, fp, [(dp, 480000) for dp in c3_pcm])
+                return sum(st.full_n_tokens(i) for st in c3_states for i in range(st.full_n_segments()))
+        c3_step(); sync(); barrier()
+        t1 = time.perf_counter()
+        c3_tok = c3_step()
+        sync(); barrier()
+        c3_dt = reduce_max(time.perf_counter() - t1)
+        c3_tok = reduce_sum(c3_tok)
+        out["config3"] = {"workload": "8 x 30 s chunks per GPU in one whisper_amd_full_batch call per rank (BASELINE config 3: 64 chunks over 8 GPUs)",
+                          "chunks": 8 * world, "value": round(30.0 * 8 * world / c3_dt, 1), "unit": "x real-time (aggregate over all GPUs)",
+                          "ms": round(1e3 * c3_dt, 1), "tokens": c3_tok, "tokens_per_s": round(c3_tok / c3_dt, 1), "scaling": "weak"}
+        if not args.stub:
+            for st_ in c3_states:
+                st_.free()
+
+    if args.stub:
+        if rank == 0:
+            out["stub"] = {"image_checksum": eng.sum, "chunk_ids_rank0": my_ids}
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            ok = reduce_sum(1 if eng.sum == reduce_max(float(eng.sum)) else 0)      # every rank parsed the image rank 0 sent
+            if rank == 0 and ok != world:
+                sys.exit("weight broadcast: %d of %d ranks hold rank 0's image" % (ok, world))
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if rank == 0 and world == 1:
         # ---- the same step with the PCM handed over in HOST memory (what whisper-rs does): + 1.92 MB H2D per chunk
@@ -259,7 +341,7 @@ def main():
                                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                                "traffic": traffic, "traffic_source": traffic_src, "bytes_per_step": dbytes, "ms_per_step_device": round(ms.value, 4),
                                "ms_per_token_wall_in_full": round(dec_ms_wall, 4)}
-        # ---- throughput mode on the same GPU: 4 independent chunks transcribed concurrently (one stream + host thread each)
+        # ---- throughput mode on the same GPU: 8 independent chunks transcribed together (one host thread each, single-token steps in lock step)
         if world == 1 and not args.no_concurrent:
             try:
                 NB = 8      # BASELINE config 3: 64 chunks over 8 GPUs = 8 per GPU
@@ -279,6 +361,13 @@ def main():
                                             "vs_single_chunk": round(30.0 * NB / tdt / rtf, 2),
                                             "bytes_per_pass": int(2 * (14 * shape["dec"] * shape["d"] ** 2 + shape["n_vocab"] * shape["d"]) + rows_pp * (4 * shape["dec"] * 1500 * shape["d"] + 4 * shape["dec"] * shape["d"] * 110)),
                                             "note": "lock-step batched decode: one decoder pass reads every weight row once for all chunks' tokens (W + B (KVx + KVs) bytes per pass)"}
+                out["concurrent_chunks"]["tokens_per_s"] = round(ntk / tdt, 1)
+                out["concurrent_chunks"]["passes_one_launch"] = int(lib.whisper_amd_batch_one_launch(ctx.ptr))
+                import bench_configs
+                # the 8-row pass itself (HIP events around back-to-back launches, rows of 8 different chunks) against W + 8 (KVx + KVs)
+                out["concurrent_chunks"]["roofline"] = bench_configs.rows_roofline(lib, ctx, tst, shape, NB, 110, False)
+                # ... and the 5-row pass of a beam-search / best_of step (rows of ONE chunk)
+                out["beam5_step"] = bench_configs.rows_roofline(lib, ctx, tst, shape, 5, 64, True)
                 for s_ in tst:
                     s_.free()
             except Exception as ex:  # extension only; never fail the headline
@@ -359,6 +448,20 @@ def main():
                                              "at the best thread count of the sweep" % (rtok, rdt),
                                    "host_cores": cores, "thread_sweep": {str(k): v for k, v in sweep.items()},
                                    "token_ids_identical_to_gpu": bool(same)}
+        # ---- BASELINE configs 4 and 5 (tools/bench_configs.py), each with the CPU reference beside it at the thread count of the sweep above
+        if world == 1 and not args.no_configs and args.model == "small":
+            import bench_configs
+            ref_lib = None
+            if not args.no_cpu_baseline and os.path.exists(ref_path):
+                ref_lib = W.load_library(ref_path)
+            nthr_c = out.get("cpu_baseline", {}).get("cores", 16)
+            for name, fn in (("config4", bench_configs.config4), ("config5", bench_configs.config5)):
+                t1 = time.perf_counter()
+                try:
+                    out[name] = fn(W, lib, ref_lib, hip, nthr_c, with_cpu=ref_lib is not None)
+                except Exception as ex:  # extension only; never fail the headline
+                    out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                out[name]["wall_s"] = round(time.perf_counter() - t1, 1)
         print(json.dumps(out), flush=True)
         if args.json_out:
             with open(args.json_out, "w") as f:

@@ -152,6 +152,9 @@ def test_quantised_five_and_eight_decoders(wrs, amd_lib, gold, gen):
             st = ctx.create_state()
             st.full(_params(wrs, amd_lib, kw), wsynth.synth_audio(480000, aseed))
             assert _segs(st) == gold["s128_q5_0"]["%s_seed%d" % (tag, aseed)], (tag, aseed)
+            served, back = st.rows_stats()          # the several-decoder steps as ONE launch (the quantised form of wa_rows.hip)
+            if kw.get("strategy", 0) == 1: assert served > 0, (tag, aseed, served, back)
+            assert back <= 2, (tag, aseed, served, back)
             st.free()
     ctx.free()
 

@@ -53,7 +53,7 @@ for step, tok in enumerate(toks):
         rcB = lib.whisper_amd_rows_debug(ctx.ptr, meg.ptr, B, tok, n_past, gB.ctypes.data, lB.ctypes.data)
         gB = gB.reshape(L, 8, B, 2 * d); lB = lB.reshape(B, nv)
         first = None
-        for l in range(L):
+        for l in (range(L) if ":" not in name else []):      # (quantised models: other granule formats than the one-row step's - logits only)
             for e in range(8):
                 for b in range(B):
                     a = g1[l, e, :sizes[e]] & 0xffffffff; v = gB[l, e, b, :sizes[e]] & 0xffffffff

@@ -310,17 +310,19 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
                      uint32_t kv_size, bool wait_slot) {
     const auto & m = ctx.model;
     const auto & hp = m.hp;
-    if (B < 1 || B > WA_ROWS_MAX || n_out < 1 || n_out > B || !bst.rows_enabled || m.wtype != 1 || T < 1 || (T >> 5) > 47 || T > cross_tpad) return 0;
+    if (B < 1 || B > WA_ROWS_MAX || n_out < 1 || n_out > B || !bst.rows_enabled || T < 1 || (T >> 5) > 47 || T > cross_tpad) return 0;
     for (int i = 0; i < B; ++i)
         if (rows[i].n_kv < 1 || rows[i].n_kv > WA_ROWS_MAXKV || rows[i].kv_head < 0 || rows[i].kv_head >= rows[i].n_kv) return 0;
     const int n_wg = std::min(m.n_cu, 256);
     wa_rows_args a;
     memset(&a, 0, sizeof(a));
-    if (wa_rows_lds_bytes(hp.n_text_state, B, n_wg, &a.slot_bytes) == 0) return 0;
+    const int quant = m.wtype != 1 ? 1 : 0;
+    if (wa_rows_lds_bytes(hp.n_text_state, B, n_wg, quant, &a.slot_bytes) == 0) return 0;
     if (!wa_rows_prepare(ctx, bst)) return 0;
     a.layers = (const wa_mega_layer *) m.d_mega_layers;
     a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
-    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu; a.te_d = nullptr; a.quant = 0;
+    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu; a.te_d = nullptr; a.quant = quant;
+    if (quant) { a.te = (const wa_f16 *) m.te_q.qs; a.te_d = m.te_q.qd; }
     a.kv_layer_stride = (unsigned long long) kv_size * hp.n_text_state;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * cross_tpad * 64; a.cross_tpad = cross_tpad; a.T = T;
     a.granules = bst.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = bst.d_rows_cgr;
@@ -453,7 +455,7 @@ struct wa_batcher {
     std::mutex m;
     std::condition_variable cv;
     int n_members = 0;                              // threads that may still submit
-    struct req { whisper_state * st; int token, pos, n_kv, kv_head; int result; };      // result: 0 pending, 1 logits delivered, -1 not served
+    struct req { whisper_state * st; int token, pos, n_kv, kv_head; int result; const float * row; };      // result: 0 pending, 1 served (`row`: its logits in the pass's staging buffer), -1 not served
     std::vector<req *> waiting;
     long n_steps = 0, n_rows = 0, n_one_launch = 0;       // passes, the token rows they served, passes that were ONE launch (wa_rows.hip)
     // the pass for B rows as a hipGraph (122 launches for ggml-small): captured on first use, replayed while T and the cell count stay
@@ -463,7 +465,7 @@ struct wa_batcher {
 };
 
 wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
-    if (ctx.model.wtype != 1 || ctx.model.n_loaded == 0 || n_members < 2) return nullptr;
+    if (ctx.model.n_loaded == 0 || n_members < 2) return nullptr;
     auto * b = new wa_batcher();
     b->ctx = &ctx; b->n_members = n_members;
     b->bst = whisper_init_state(&ctx);
@@ -523,7 +525,8 @@ static void batcher_run(wa_batcher & b) {
             served = rows_step(ctx, bs, B, rr, B, nullptr, T, bs.cross_tpad, s0.kv_self.size, true) == 1;
             if (served) b.n_one_launch += 1;
         }
-        if (!served) {
+        if (!served && ctx.model.wtype != 1) ok = false;       // (the launch sequence of a quantised model has no per-row K / V form: the members decode alone)
+        else if (!served) {
         (void) hipMemcpyAsync(bs.d_tok, h_tok, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(bs.d_pos, h_pos, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(bs.d_rows, h_rows, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
@@ -554,14 +557,9 @@ static void batcher_run(wa_batcher & b) {
         if (!ok) b.graphs_ok = false;
         }
     }
-    for (int i = 0; i < B; ++i) {
-        if (ok) {
-            auto & lg = run[i]->st->logits;
-            lg.resize(n_vocab);
-            memcpy(lg.data(), bs.h_logits_pinned + (size_t) i * n_vocab, (size_t) n_vocab * sizeof(float));
-        }
-        run[i]->result = ok ? 1 : -1;
-    }
+    // every member copies ITS row out on its own thread (the staging buffer is not written again before all of them are back with their next
+    // requests): eight 200 KB copies one after the other cost the group 0.15 ms per pass
+    for (int i = 0; i < B; ++i) { run[i]->row = bs.h_logits_pinned + (size_t) i * n_vocab; run[i]->result = ok ? 1 : -1; }
     b.n_steps += 1; b.n_rows += B;
 }
 
@@ -569,11 +567,16 @@ static void batcher_run(wa_batcher & b) {
 static int batcher_step(wa_batcher & b, whisper_state & st, int token, int pos, int n_kv, int kv_head) {
     std::unique_lock<std::mutex> lk(b.m);
     if (b.n_members < 2) return 0;                  // the last chunk still decoding: nothing to share a pass with
-    wa_batcher::req r = { &st, token, pos, n_kv, kv_head, 0 };
+    wa_batcher::req r = { &st, token, pos, n_kv, kv_head, 0, nullptr };
     b.waiting.push_back(&r);
     if ((int) b.waiting.size() >= b.n_members) { batcher_run(b); b.cv.notify_all(); }
     else b.cv.wait(lk, [&] { return r.result != 0; });
-    return r.result == 1 ? 1 : 0;
+    lk.unlock();
+    if (r.result != 1) return 0;
+    const size_t n_vocab = (size_t) b.ctx->model.hp.n_vocab;
+    st.logits.resize(n_vocab);
+    memcpy(st.logits.data(), r.row, n_vocab * sizeof(float));
+    return 1;
 }
 // a member is done (or failed): the others no longer wait for it
 void wa_batcher_leave(wa_batcher * b) {
@@ -647,9 +650,9 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     for (size_t i = 0; i < (size_t) n_tokens * n_kv && !need_mask; ++i) need_mask = h_mask[i] != 0;
     const bool steady = n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads;
     bool done = false, from_batcher = false;
-    if (steady && st.batcher && m.wtype == 1) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    if (steady && st.batcher) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done && steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
-    if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && m.wtype == 1 && n_kv <= WA_ROWS_MAXKV) {
+    if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && n_kv <= WA_ROWS_MAXKV) {
         // one token per live decoder (beam search, best_of, the bench's small batches): all rows in ONE launch (wa_rows.hip)
         if (need_mask) (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
         wa_rows_row rr[WA_MAX_DECODERS];
@@ -824,10 +827,12 @@ static bool rows_probe_args(whisper_context & ctx, whisper_state & own, whisper_
     const int T = own.enc_n_ctx > 0 ? own.enc_n_ctx : hp.n_audio_ctx;
     memset(&a, 0, sizeof(a));
     if (B < 1 || B > WA_ROWS_MAX || !own.rows_enabled || n_past < 0 || n_past + 1 > (int) own.kv_self.size || n_past + 1 > WA_ROWS_MAXKV || (T >> 5) > 47) return false;
-    if (wa_rows_lds_bytes(hp.n_text_state, B, std::min(m.n_cu, 256), &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, own)) return false;
+    const int quant = m.wtype != 1 ? 1 : 0;
+    if (wa_rows_lds_bytes(hp.n_text_state, B, std::min(m.n_cu, 256), quant, &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, own)) return false;
     a.layers = (const wa_mega_layer *) m.d_mega_layers;
     a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
-    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu;
+    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu; a.quant = quant;
+    if (quant) { a.te = (const wa_f16 *) m.te_q.qs; a.te_d = m.te_q.qd; }
     a.kv_layer_stride = (unsigned long long) own.kv_self.size * hp.n_text_state;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * own.cross_tpad * 64; a.cross_tpad = own.cross_tpad; a.T = T;
     a.granules = own.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = own.d_rows_cgr;

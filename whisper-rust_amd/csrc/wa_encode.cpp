@@ -49,7 +49,7 @@ bool wa_rows_prepare(whisper_context & ctx, whisper_state & st) {
     if (st.d_rows_gr) return true;
     const auto & hp = ctx.model.hp;
     const int dt = hp.n_text_state, Ht = hp.n_text_head;
-    const size_t row_gr = (size_t) (ctx.model.wtype != 1 ? 4 : 2) * dt;
+    const size_t row_gr = (size_t) 2 * dt;
     if (!dev_alloc(st.d_rows_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * WA_ROWS_MAX * row_gr) ||
         !dev_alloc(st.d_rows_cgr, (size_t) hp.n_text_layer * WA_ROWS_MAX * Ht * WA_ROWS_CGR) || !dev_alloc(st.d_rows_status, 16)) {
         dev_free(st.d_rows_gr); dev_free(st.d_rows_cgr); dev_free(st.d_rows_status);
@@ -116,7 +116,7 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
             {   // the several-rows form shares the one-launch step's preconditions (its buffers come with the first such pass: wa_rows_prepare)
                 const char * r = getenv("WHISPER_AMD_NO_ROWS");
                 int slot = 0;
-                st.rows_enabled = !(r && r[0] == '1') && ctx.model.wtype == 1 && wa_rows_lds_bytes(dt, 2, std::min(ctx.model.n_cu, 256), &slot) != 0;
+                st.rows_enabled = !(r && r[0] == '1') && wa_rows_lds_bytes(dt, 2, std::min(ctx.model.n_cu, 256), ctx.model.wtype != 1 ? 1 : 0, &slot) != 0;
             }
             // (the copy stream, events and pinned buffers of the host overlap are created on first use, wa_spec_begin: a state that
             //  only ever runs inside whisper_amd_full_batch keeps ONE stream - extra streams cost the concurrent chunks their overlap)

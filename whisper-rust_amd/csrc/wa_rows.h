@@ -36,7 +36,7 @@ struct wa_rows_args {
     const float * te_d; int quant;
     unsigned long long kv_layer_stride, cross_layer_stride;
     int cross_tpad, T;
-    unsigned long long * granules; int row_gr;          // [layer][8][B][row_gr] hand-off granules (row_gr = 2 d; 4 d for a quantised model)
+    unsigned long long * granules; int row_gr;          // [layer][8][B][row_gr] hand-off granules (row_gr = 2 d)
     unsigned long long * cross_gr;                      // [layer][B][head][WA_ROWS_CGR]
     float * logits;                                     // [B][n_vocab]
     unsigned * status;                                  // [0] 0 = ok, else the code of the hand-off that timed out; [1] = seq once the launch has run
@@ -49,6 +49,6 @@ struct wa_rows_args {
 
 // LDS the kernel needs for B rows of a d-wide model with `n_wg` workgroups; 0 when it does not fit (the caller keeps the launch sequence).
 // slot_bytes = size of one of the two weight slots.
-size_t wa_rows_lds_bytes(int d, int B, int n_wg, int * slot_bytes);
+size_t wa_rows_lds_bytes(int d, int B, int n_wg, int quant, int * slot_bytes);
 // n_wg workgroups of 512 threads, all resident at once (1 per CU); false: shape not supported
 bool wa_launch_decode_rows(hipStream_t s, const wa_rows_args & a, int n_wg);

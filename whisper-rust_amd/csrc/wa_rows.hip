@@ -103,81 +103,6 @@ __device__ __forceinline__ void mb_gather(mb_ctl & c, gu64 * edge, int B, int pe
 }
 
 // -------------------------------------------------------------------------------------------------
-// LayerNorm of ONE token row by ONE wave (ops.cpp:3225-3242 semantics as wa_exact.hip: wa_ln_stats - F64 sums in any order, accepted
-// when certified order-independent, else redone in index order): the row comes from granules (or the embeddings), stays in registers,
-// and leaves as F16 in `dst`.  The in-order fallback walks the registers lane by lane (no LDS copy of the row).
-// -------------------------------------------------------------------------------------------------
-template <int NP>
-__device__ __forceinline__ double mb_seq_sum(const float (&xv)[NP], int d, bool squares, float mean) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-#pragma nounroll
-        for (int j0 = 0; j0 < 64; j0 += 8) {
-            double e[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[k]), j0 + j));
-                const float a = x - mean;
-                e[j] = 64 * k + j0 + j < d ? (squares ? (double) (a * a) : (double) x) : 0.0;      // (+0.0 leaves an IEEE sum unchanged)
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t += e[j];
-        }
-    }
-    return t;
-}
-template <int NP>
-__device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_row /* null: embeddings */, const float * lnp /* LDS: gamma | beta, each d floats in whole KB */, const float * gw_g, const float * gb_g /* global, when non-null */,
-                                          int b, int lane, wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code) {
-    const int d = A->d;
-    float xv[NP];
-    if (edge_row) {
-        unsigned v[NP];
-        mb_sweep<NP>(edge_row, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
-    } else {                    // k_dec_embed: token embedding + positional embedding
-        const gch te = (gch) A->te + (size_t) A->rows[b].token * d;
-        const gcf pe = (gcf) A->pe + (size_t) A->rows[b].pos * d;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; const float e = h2f(te[ic]) + pe[ic]; xv[k] = i < d ? e : 0.0f; }
-        if (xres_b) {           // the residual values of the rows this workgroup owns in the d-row products
-#pragma unroll
-            for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k; if (i >= row_d && i < row_d + r_d && i < d) xres_b[i - row_d] = xv[k]; }
-        }
-    }
-    double s = 0.0, a = 0.0;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
-    s = wave_sum_d(s); a = wave_sum_d(a);
-    float mean, mean_hi;
-    if (!wa_sum_bounds(s, a, d, mean, mean_hi, A->rn_d)) {
-        bool same = true;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) same &= wa_mean_indifferent(xv[k], mean, mean_hi);
-        if (!__all(same)) { s = mb_seq_sum<NP>(xv, d, false, 0.0f); mean = (float) (s / (double) d); }
-    }
-    double s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
-    s2 = wave_sum_d(s2);
-    float variance;
-    if (!wa_sum_certain(s2, s2, d, variance, A->rn_d)) { s2 = mb_seq_sum<NP>(xv, d, true, mean); variance = (float) (s2 / (double) d); }
-    const float scale = 1.0f / sqrtf(variance + A->eps);
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int i = lane + 64 * k;
-        float y = xv[k] - mean;
-        y = y * scale;
-        const int ic = i < d ? i : 0;
-        y = y * (gw_g ? ((gcf) gw_g)[ic] : lnp[ic]);
-        y = y + (gb_g ? ((gcf) gb_g)[ic] : lnp[((d + 255) & ~255) + ic]);      // (beta: behind gamma's whole LDS-DMA pieces)
-        if (i < d) dst[i] = f2h(y);
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // Weight rows -> LDS by LDS-DMA (wave 7).  The LDS image is rows of `pitch` bytes + MB_PAD, lane-linear in 16-byte cells (an LDS-DMA
 // instruction writes 64 consecutive cells): every lane works out which (row, column) its cell is and reads THAT address; cells of the
 // padding (and behind the last row) read a valid dummy address.
@@ -279,6 +204,172 @@ __device__ __forceinline__ void mb_dot16(const unsigned char * wrow, const wa_f1
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Quantised models (Q5_0 / Q8_0 files; contract: wa_quant.hip - ggml_vec_dot_q5_0_q8_0 / q8_0_q8_0 in the AVX2 order).  A weight row is
+// [lane u = 0..7][block][4] signed bytes + [block] F32 scales; an operand row sits in LDS quantised to Q8_0 in the same order
+// (quads [u][block | 8 words apart][4], then the block scales).  Lane u chains  acc = fma(dw dx, (float) dot4(w, x), acc)  over the blocks in
+// order; three DPP adds are hsum_float_8.
+// -------------------------------------------------------------------------------------------------
+typedef int   mq_i4 __attribute__((ext_vector_type(4)));
+typedef float mq_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int mq_ld(int nb) { return nb | 8; }                                   // words between the quad rows u of an operand row
+__host__ __device__ __forceinline__ size_t mq_row_bytes(int nb) { return (size_t) 32 * (nb | 8) + (size_t) 4 * nb; }
+__device__ __forceinline__ unsigned * mq_quads(unsigned char * op, int nb, int u) { return (unsigned *) op + u * mq_ld(nb); }
+__device__ __forceinline__ float * mq_scales(unsigned char * op, int nb) { return (float *) (op + (size_t) 32 * mq_ld(nb)); }
+// quantize_row_q8_0 (arch/x86/quants.c) of a 32-element block held one value per lane of a half-wave (as wa_q8_store): the quad of lanes
+// 4k..4k+3 packed over DPP into lane 4k; returns the block's scale (rounded through F16).  All lanes take part.
+__device__ __forceinline__ unsigned mq_quant32(float y, float & dq) {
+    float a = fabsf(y);
+    a = fmaxf(a, dpp_f32<0x128>(a)); a = fmaxf(a, dpp_f32<0x124>(a)); a = fmaxf(a, dpp_f32<0x122>(a)); a = fmaxf(a, dpp_f32<0x121>(a));
+    a = fmaxf(a, __shfl_xor(a, 16, 32));
+    const float id = a != 0.0f ? 127.f / a : 0.0f;
+    dq = h2f(f2h(a / 127.f));
+    const unsigned q = (unsigned) (int) rintf(y * id) & 0xffu;
+    return q | (dpp_u32<0x101>(q) << 8) | (dpp_u32<0x102>(q) << 16) | (dpp_u32<0x103>(q) << 24);      // row_shl:1..3
+}
+template <int BC>
+__device__ __forceinline__ void mb_dotq8(const unsigned char * wq, const unsigned char * wd, const unsigned char * xop, size_t op_bytes, int u, int nb,
+                                         int b0, int B, float (&res)[BC]) {
+    float acc[BC];
+    const unsigned char * xq[BC], * xd[BC];
+#pragma unroll
+    for (int j = 0; j < BC; ++j) {
+        acc[j] = 0.0f;
+        const unsigned char * r = xop + (size_t) (b0 + j < B ? b0 + j : B - 1) * op_bytes;
+        xq[j] = r + (size_t) u * mq_ld(nb) * 4; xd[j] = r + (size_t) 32 * mq_ld(nb);
+    }
+#pragma unroll 2
+    for (int c = 0; c < (nb >> 2); ++c) {
+        const mq_i4 w = *(const mq_i4 *) (wq + 16 * c);
+        const mq_f4 sd = *(const mq_f4 *) (wd + 16 * c);
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+            const mq_i4 x = *(const mq_i4 *) (xq[j] + 16 * c);
+            const mq_f4 dx = *(const mq_f4 *) (xd[j] + 16 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] = fmaf(sd[e] * dx[e], (float) __builtin_amdgcn_sdot4(w[e], x[e], 0, false), acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BC; ++j) {
+        float v = acc[j];
+        v = v + dpp_f32<0x104>(v);          // row_shl:4  acc[l] + acc[l+4]
+        v = v + dpp_f32<0x102>(v);
+        res[j] = v + dpp_f32<0x101>(v);
+    }
+}
+// product tasks of a quantised chunk: the slot holds the rows' quants (row stride K + MB_PAD), then - `soff` bytes in - their block scales
+template <int BC, typename EPI>
+__device__ __forceinline__ void mb_products_q(const unsigned char * slot, int soff, int Rc, int row_base, int N, const float * bias_l, const float * scale_l,
+                                              const unsigned char * xop, size_t op_bytes, int K, int B, int wave, int lane, EPI epi) {
+    const int nb = K >> 5, stride_q = K + MB_PAD, stride_s = 4 * nb + MB_PAD;
+    const int groups = (Rc + 7) >> 3, nsub = (B + BC - 1) / BC, per = (B + nsub - 1) / nsub, ntasks = groups * nsub;
+    const int u = lane & 7;
+    for (int t = wave; t < ntasks; t += MB_NCW) {
+        const int g = t / nsub, sb = t - g * nsub, b0 = sb * per, b1 = min(B, b0 + per);
+        const int ri = g * 8 + (lane >> 3), rr = ri < Rc ? ri : Rc - 1;
+        const bool has = ri < Rc && row_base + ri < N && u == 0;
+        const float bv = bias_l[ri < 64 ? ri : 63], sv = scale_l ? scale_l[ri < 64 ? ri : 63] : 1.0f;
+        float res[BC];
+        mb_dotq8<BC>(slot + (size_t) rr * stride_q + (size_t) u * nb * 4, slot + soff + (size_t) rr * stride_s, xop, op_bytes, u, nb, b0, B, res);
+        epi(res, b0, b1, row_base + ri, has, bv, sv);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// LayerNorm of ONE token row by ONE wave (ops.cpp:3225-3242 semantics as wa_exact.hip: wa_ln_stats - F64 sums in any order, accepted
+// when certified order-independent, else redone in index order): the row comes from granules (or the embeddings), stays in registers,
+// and leaves as F16 in `dst`.  The in-order fallback walks the registers lane by lane (no LDS copy of the row).
+// -------------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ double mb_seq_sum(const float (&xv)[NP], int d, bool squares, float mean) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma nounroll
+        for (int j0 = 0; j0 < 64; j0 += 8) {
+            double e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[k]), j0 + j));
+                const float a = x - mean;
+                e[j] = 64 * k + j0 + j < d ? (squares ? (double) (a * a) : (double) x) : 0.0;      // (+0.0 leaves an IEEE sum unchanged)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += e[j];
+        }
+    }
+    return t;
+}
+template <int NP, bool Q = false>         // Q: the normalised row leaves as Q8_0 (the next product's operand), not as F16
+__device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_row /* null: embeddings */, const float * lnp /* LDS: gamma | beta, each d floats in whole KB */, const float * gw_g, const float * gb_g /* global, when non-null */,
+                                          int b, int lane, wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code) {
+    const int d = A->d;
+    float xv[NP];
+    if (edge_row) {
+        unsigned v[NP];
+        mb_sweep<NP>(edge_row, [&](int k) { const int i = lane + 64 * k; return i < d ? i : -1; }, c, lane, v, code);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) xv[k] = (lane + 64 * k < d) ? __uint_as_float(v[k]) : 0.0f;
+    } else {                    // k_dec_embed: token embedding + positional embedding
+        const gcf pe = (gcf) A->pe + (size_t) A->rows[b].pos * d;
+        if constexpr (!Q) {
+            const gch te = (gch) A->te + (size_t) A->rows[b].token * d;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; const float e = h2f(te[ic]) + pe[ic]; xv[k] = i < d ? e : 0.0f; }
+        } else {                // k_dec_embed_q: the row dequantised (q * d, ggml-quants.c)
+            const int nb = d >> 5;
+            const GAS int8_t * tq = (const GAS int8_t *) A->te + (size_t) A->rows[b].token * 8 * nb * 4;
+            const gcf td = (gcf) A->te_d + (size_t) A->rows[b].token * nb;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int i = lane + 64 * k, ic = i < d ? i : d - 1, bb = ic >> 5, el = ic & 31;
+                const float e = (float) (int) tq[(((size_t) (el >> 2)) * nb + bb) * 4 + (el & 3)] * td[bb] + pe[ic];
+                xv[k] = i < d ? e : 0.0f;
+            }
+        }
+        if (xres_b) {           // the residual values of the rows this workgroup owns in the d-row products
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k; if (i >= row_d && i < row_d + r_d && i < d) xres_b[i - row_d] = xv[k]; }
+        }
+    }
+    double s = 0.0, a = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
+    s = wave_sum_d(s); a = wave_sum_d(a);
+    float mean, mean_hi;
+    if (!wa_sum_bounds(s, a, d, mean, mean_hi, A->rn_d)) {
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) same &= wa_mean_indifferent(xv[k], mean, mean_hi);
+        if (!__all(same)) { s = mb_seq_sum<NP>(xv, d, false, 0.0f); mean = (float) (s / (double) d); }
+    }
+    double s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
+    s2 = wave_sum_d(s2);
+    float variance;
+    if (!wa_sum_certain(s2, s2, d, variance, A->rn_d)) { s2 = mb_seq_sum<NP>(xv, d, true, mean); variance = (float) (s2 / (double) d); }
+    const float scale = 1.0f / sqrtf(variance + A->eps);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int i = lane + 64 * k;
+        float y = xv[k] - mean;
+        y = y * scale;
+        const int ic = i < d ? i : 0;
+        y = y * (gw_g ? ((gcf) gw_g)[ic] : lnp[ic]);
+        y = y + (gb_g ? ((gcf) gb_g)[ic] : lnp[((d + 255) & ~255) + ic]);      // (beta: behind gamma's whole LDS-DMA pieces)
+        if constexpr (!Q) { if (i < d) dst[i] = f2h(y); }
+        else {                  // a half-wave holds one 32-element block (d % 64 == 0: every block of k < d / 64 is whole)
+            float dq;
+            const unsigned w = mq_quant32(i < d ? y : 0.0f, dq);
+            const int nb = d >> 5, blk = (lane >> 5) + 2 * k;
+            if (i < d && (lane & 3) == 0) mq_quads((unsigned char *) dst, nb, (lane & 31) >> 2)[blk] = w;
+            if (i < d && (lane & 31) == 0) mq_scales((unsigned char *) dst, nb)[blk] = dq;
+        }
+    }
+}
+
 // The product tasks of one weight chunk (Rc rows starting at matrix row `row_base`, in `slot`): task = (group of 64 / LPR weight rows, sub-batch of
 // the token rows), dealt over the computing waves.  epi(values, first token row, end token row, matrix row, lane holds results, bias, scale) - called
 // by every lane; bias / scale of the chunk's rows sit behind the weights in the slot (wave 7 brought them along).
@@ -324,7 +415,9 @@ __device__ __forceinline__ float mb_score(const u32x4 & ka, const u32x4 & kb, co
     return ((t0 + t1) + (t2 + t3)) * scale;
 }
 
-// the head's 64 outputs from the 32 chain sums + the leftover cells in F64, index order (vec.cpp:221-223), by threads 0..63; published packed
+// the head's 64 outputs from the 32 chain sums + the leftover cells in F64, index order (vec.cpp:221-223), by threads 0..63; published packed.
+// Q: the 64 outputs are two Q8_0 blocks of the out-projection's operand: quantised HERE, once (8 quads + the scale = 9 granules per block).
+template <bool Q = false>
 __device__ __forceinline__ void mb_attn_finish(const float * part, const wa_f16 * vleft /* [nl][64] LDS */, const wa_f16 * pleft /* [nl] */, int nl,
                                                gu64 * edge_row, int h, unsigned seq, int tid) {
     if (tid < 64) {
@@ -333,9 +426,17 @@ __device__ __forceinline__ void mb_attn_finish(const float * part, const wa_f16 
         for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
         double sumf = (double) wa_tree32(s32);
         for (int cc = 0; cc < nl; ++cc) sumf += (double) (h2f(vleft[cc * 64 + tid]) * h2f(pleft[cc]));
-        const unsigned hv = (unsigned) f2h((float) sumf);
-        const unsigned hi = dpp_u32<0x101>(hv);          // row_shl:1: lane i reads lane i + 1
-        if ((tid & 1) == 0) gr_store(edge_row + ((h * 64 + tid) >> 1), seq, (hv & 0xffffu) | (hi << 16));
+        if constexpr (Q) {
+            float dq;
+            const unsigned w = mq_quant32((float) sumf, dq);
+            gu64 * eb = edge_row + (size_t) (2 * h + (tid >> 5)) * 9;
+            if ((tid & 3) == 0) gr_store(eb + ((tid & 31) >> 2), seq, w);
+            if ((tid & 31) == 0) gr_store(eb + 8, seq, __float_as_uint(dq));
+        } else {
+            const unsigned hv = (unsigned) f2h((float) sumf);
+            const unsigned hi = dpp_u32<0x101>(hv);          // row_shl:1: lane i reads lane i + 1
+            if ((tid & 1) == 0) gr_store(edge_row + ((h * 64 + tid) >> 1), seq, (hv & 0xffffu) | (hi << 16));
+        }
     }
 }
 
@@ -344,6 +445,7 @@ __device__ __forceinline__ void mb_attn_finish(const float * part, const wa_f16 
 // tokens come from the row's own cells in HBM; the cells written by THIS launch - the row's own and those of every other row that shares
 // its cache (earlier tokens of a small batch; other beams, which the mask hides) - arrive as granules, like the query.
 // -------------------------------------------------------------------------------------------------
+template <bool Q = false>
 __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int tid) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float  * part = (float *) area;                                  // [32][64]
@@ -517,7 +619,7 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
         for (int i = 0; i < 4; ++i) part[(r0 + i) * 64 + lane] = acc[i];
     }
     mb_barrier();
-    mb_attn_finish(part, vleft, p16 + np, nl, mb_edge(A, l, E_AO) + (size_t) b * A->row_gr, h, c.seq, tid);
+    mb_attn_finish<Q>(part, vleft, p16 + np, nl, mb_edge(A, l, E_AO) + (size_t) b * A->row_gr, h, c.seq, tid);
     mb_barrier();
 }
 
@@ -547,6 +649,7 @@ __device__ __forceinline__ void mb_cross_load(mb_kargs A, int l, int b, int h, i
     for (int s = 0; s < MB_CSTEPS; ++s) { const int sc_ = s < nsteps ? s : (nsteps > 0 ? nsteps - 1 : 0); R.vv[s] = *(const GAS unsigned short *) (vp + (size_t) (32 * sc_ + 8 * w + wave) * 64 + lane); }
 }
 
+template <bool Q = false>
 __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int w, int tid, bool tw, const mb_cross_regs & R) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned seq = c.seq;
@@ -682,7 +785,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         }
         mb_barrier();
         MB_TC(9);
-        mb_attn_finish(part, vleft, pleft, nl, mb_edge(A, l, E_AO2) + (size_t) b * A->row_gr, h, seq, tid);
+        mb_attn_finish<Q>(part, vleft, pleft, nl, mb_edge(A, l, E_AO2) + (size_t) b * A->row_gr, h, seq, tid);
         MB_TC(10);
     }
     mb_barrier();
@@ -760,12 +863,69 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
     }
 }
 
+// the same for a quantised token embedding: a row = 8 lanes x (quads [nb], F32 block scales [nb]) streamed in pieces of 24 blocks; the token
+// rows' final LayerNorm outputs sit in `xop` quantised (mb_ln_row<.., true>)
+template <int BT>
+__device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xop, size_t op_bytes, int B, int lane, int wave) {
+    const int d = A->d, nb = d >> 5, nbat = (nb + 23) / 24, n_vocab = A->n_vocab;
+    const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
+    GAS float * logits = (GAS float *) A->logits;
+    unsigned pfa[48], pfb[48];
+    auto grp = [&](int j) { return wg + nwg * (wave + MB_NW * j); };
+    int n_items = 0;
+    for (int j = 0; grp(j) < NG; ++j) n_items += nbat;
+    auto load = [&](int it, unsigned (&buf)[48]) {
+        const int j = it / nbat, bt = it - j * nbat, row = grp(j) * 8 + (lane >> 3), rc = row < n_vocab ? row : 0;
+        const GAS unsigned * wl = (const GAS unsigned *) A->te + ((size_t) rc * 8 + u) * nb;
+        const GAS unsigned * dl = (const GAS unsigned *) A->te_d + (size_t) rc * nb;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) { const int bb = bt * 24 + k, bc = bb < nb ? bb : nb - 1; buf[k] = wl[bc]; buf[24 + k] = dl[bc]; }
+    };
+    float acc[BT];
+    const unsigned char * xq[BT], * xd[BT];
+#pragma unroll
+    for (int m = 0; m < BT; ++m) { const unsigned char * r = xop + (size_t) (m < B ? m : B - 1) * op_bytes; xq[m] = r + (size_t) u * mq_ld(nb) * 4; xd[m] = r + (size_t) 32 * mq_ld(nb); }
+    auto one = [&](int it, unsigned (&buf)[48]) {
+        const int j = it / nbat, bt = it - j * nbat;
+        if (bt == 0) {
+#pragma unroll
+            for (int m = 0; m < BT; ++m) acc[m] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            const int bb = bt * 24 + k;
+            if (bb < nb) {
+#pragma unroll
+                for (int m = 0; m < BT; ++m)
+                    acc[m] = fmaf(__uint_as_float(buf[24 + k]) * ((const float *) xd[m])[bb], (float) __builtin_amdgcn_sdot4((int) buf[k], ((const int *) xq[m])[bb], 0, false), acc[m]);
+            }
+        }
+        if (bt == nbat - 1) {
+            const int row = grp(j) * 8 + (lane >> 3);
+#pragma unroll
+            for (int m = 0; m < BT; ++m) {
+                float v = acc[m];
+                v = v + dpp_f32<0x104>(v); v = v + dpp_f32<0x102>(v); v = v + dpp_f32<0x101>(v);
+                if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = v;
+            }
+        }
+    };
+    if (n_items > 0) load(0, pfa);
+    for (int it = 0; it < n_items; it += 2) {
+        if (it + 1 < n_items) load(it + 1, pfb);
+        one(it, pfa);
+        if (it + 1 >= n_items) break;
+        if (it + 2 < n_items) load(it + 2, pfa);
+        one(it + 1, pfb);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // the kernel
 // -------------------------------------------------------------------------------------------------
-struct mb_phase { const wa_f16 * W; const float * bias; const float * scale; int N, K, r, rc, nck; };
+struct mb_phase { const wa_f16 * W; const float * D; const float * bias; const float * scale; int N, K, r, rc, nck, soff; };
 
-template <int NP>
+template <int NP, bool Q>
 __device__ __forceinline__ void mb_body(mb_kargs A_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mb_kargs A = mb_uniform(A_);
@@ -777,40 +937,46 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     const int d = A->d, L = A->n_layer, B = A->B, H = A->n_head, d4 = 4 * d, RG = A->row_gr;
     const mb_layers Ly = (mb_layers) A->layers;
 
-    // LDS: xres [8][8] f32 | lnp: gamma [d] | beta [d] f32 of the next LayerNorm | xinB [B][d] f16 (LayerNorm outputs) | area: xin [B][4d] f16 (gathered
-    // inputs) / attention scratch | slot 0 | slot 1 (weight rows, then - in the last KB - the rows' bias and scale)
+    // LDS: xres [8][8] f32 | fc1x [8][32] f32 (quantised models: a block of FC1 outputs) | lnp: gamma | beta of the next LayerNorm | xinB: B operand rows
+    // of length d (LayerNorm outputs) | area: B operand rows of length 4d (gathered inputs) / attention scratch | slot 0 | slot 1 (weight rows, then - in
+    // the last KB - the rows' bias and scale).  An operand row is [len] F16, or - quantised models - Q8_0 in the order of mb_dotq8.
     float  * xres = (float *) smem;
-    float  * lnp  = (float *) (smem + 256);
+    float  * fc1x = (float *) (smem + 256);
+    float  * lnp  = (float *) (smem + 1280);
     const size_t lnp_bytes = 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023);      // (an LDS-DMA instruction writes a whole KB: each vector ends on one)
-    wa_f16 * xinB = (wa_f16 *) (smem + 256 + lnp_bytes);
-    const size_t xinB_bytes = ((size_t) B * d * 2 + 255) & ~(size_t) 255;
-    unsigned char * area = smem + 256 + lnp_bytes + xinB_bytes;
-    wa_f16 * xin = (wa_f16 *) area;
-    size_t area_bytes = (size_t) B * d4 * 2;
+    const size_t opB = Q ? mq_row_bytes(d >> 5) : (size_t) d * 2, op4 = Q ? mq_row_bytes(d4 >> 5) : (size_t) d4 * 2;      // bytes of an operand row
+    unsigned char * xinB = smem + 1280 + lnp_bytes;
+    const size_t xinB_bytes = ((size_t) B * opB + 255) & ~(size_t) 255;
+    unsigned char * area = xinB + xinB_bytes;
+    unsigned char * xin = area;
+    size_t area_bytes = (size_t) B * op4;
     if (area_bytes < MB_ATT_BYTES) area_bytes = MB_ATT_BYTES;
     area_bytes = (area_bytes + 255) & ~(size_t) 255;
     unsigned char * slot0 = area + area_bytes;
     const int slot_bytes = A->slot_bytes;
 
-    // rows of every matrix this workgroup owns (an even count, the same for every workgroup: mg_rpw)
+    // rows of every matrix this workgroup owns (an even count, the same for every workgroup: mg_rpw).  Quantised models: the first MLP product by
+    // WHOLE Q8_0 blocks - workgroup b < 4d / 32 owns rows 32 b .. 32 b + 31 - so that a block leaves already quantised (9 granules, not 32 F32 values)
     auto rpw = [&](int N) { const int r = (N + nwg - 1) / nwg; return (r + 1) & ~1; };
-    const int r_qkv = rpw(3 * d), r_d = rpw(d), r_ff = rpw(d4);
-    const int row_qkv = wg * r_qkv, row_d = wg * r_d, row_ff = wg * r_ff;
+    const int r_qkv = rpw(3 * d), r_d = rpw(d), r_ff = Q ? 32 : rpw(d4);
+    const int row_d = wg * r_d;
     auto phase_of = [&](int l, int p) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         mb_phase ph;
         ph.scale = nullptr;
-        if (p == 0)      { ph.W = Y.qkv_w; ph.bias = Y.qkv_b; ph.scale = Y.qkv_s; ph.N = 3 * d; ph.K = d; ph.r = r_qkv; }
-        else if (p == 1) { ph.W = Y.out_w; ph.bias = Y.out_b; ph.N = d; ph.K = d; ph.r = r_d; }
-        else if (p == 2) { ph.W = Y.cq_w;  ph.bias = Y.cq_b;  ph.N = d; ph.K = d; ph.r = r_d; }
-        else if (p == 3) { ph.W = Y.co_w;  ph.bias = Y.co_b;  ph.N = d; ph.K = d; ph.r = r_d; }
-        else if (p == 4) { ph.W = Y.fc1_w; ph.bias = Y.fc1_b; ph.N = d4; ph.K = d; ph.r = r_ff; }
-        else             { ph.W = Y.fc2_w; ph.bias = Y.fc2_b; ph.N = d; ph.K = d4; ph.r = r_d; }
-        const int gp = p == 5 ? 4 : 8, stride = 2 * ph.K + MB_PAD;
-        int rc = ((slot_bytes - 1024) / stride) / gp * gp;
+        if (p == 0)      { ph.W = Y.qkv_w; ph.D = Y.qkv_d; ph.bias = Y.qkv_b; ph.scale = Y.qkv_s; ph.N = 3 * d; ph.K = d; ph.r = r_qkv; }
+        else if (p == 1) { ph.W = Y.out_w; ph.D = Y.out_d; ph.bias = Y.out_b; ph.N = d; ph.K = d; ph.r = r_d; }
+        else if (p == 2) { ph.W = Y.cq_w;  ph.D = Y.cq_d;  ph.bias = Y.cq_b;  ph.N = d; ph.K = d; ph.r = r_d; }
+        else if (p == 3) { ph.W = Y.co_w;  ph.D = Y.co_d;  ph.bias = Y.co_b;  ph.N = d; ph.K = d; ph.r = r_d; }
+        else if (p == 4) { ph.W = Y.fc1_w; ph.D = Y.fc1_d; ph.bias = Y.fc1_b; ph.N = d4; ph.K = d; ph.r = r_ff; }
+        else             { ph.W = Y.fc2_w; ph.D = Y.fc2_d; ph.bias = Y.fc2_b; ph.N = d; ph.K = d4; ph.r = r_d; }
+        const int gp = (!Q && p == 5) ? 4 : 8;
+        const int stride = Q ? ph.K + MB_PAD + (ph.K >> 3) + MB_PAD : 2 * ph.K + MB_PAD;          // LDS bytes per weight row (quantised: quants + block scales)
+        int rc = ((slot_bytes - (Q ? 3072 : 1024)) / stride) / gp * gp;
         const int rmax = (ph.r + gp - 1) / gp * gp;
         ph.rc = rc > rmax ? rmax : rc;
         ph.nck = (ph.r + ph.rc - 1) / ph.rc;
+        ph.soff = (ph.rc * (ph.K + MB_PAD) + 1023) & ~1023;                                       // (quantised) where the scales' image starts
         return ph;
     };
     // wave 7: request chunk ck of phase (l, p) into the slot of parity `par`
@@ -820,7 +986,10 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         if (row0 >= ph.N) return;
         const int R = min(ph.rc, ph.r - ck * ph.rc);
         unsigned char * slot = slot0 + (size_t) par * slot_bytes;
-        mb_dma_rows((const GAS unsigned char *) ph.W, 2 * ph.K, row0, R, ph.N, slot, lane);
+        if constexpr (Q) {
+            mb_dma_rows((const GAS unsigned char *) ph.W, ph.K, row0, R, ph.N, slot, lane);
+            mb_dma_rows((const GAS unsigned char *) ph.D, ph.K >> 3, row0, R, ph.N, slot + ph.soff, lane);
+        } else mb_dma_rows((const GAS unsigned char *) ph.W, 2 * ph.K, row0, R, ph.N, slot, lane);
         mb_dma_f32(ph.bias, row0, ph.N, (float *) (slot + slot_bytes - 512), lane);
         if (ph.scale) mb_dma_f32(ph.scale, row0, ph.N, (float *) (slot + slot_bytes - 256), lane);
     };
@@ -834,8 +1003,8 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         mb_dma_vec(w, d, lnp, lane); mb_dma_vec(b_, d, lnp + ((d + 255) & ~255), lane);
     };
     int par = 0;                 // parity of the chunk the NEXT product phase reads
-    // One product phase: `front` has filled the operand rows in LDS; per chunk: barrier (weights landed, operand visible, previous chunk's
-    // readers done) -> wave 7 requests the next chunk of the whole sequence -> waves 0..6 run the tasks.
+    // One product phase: the operand rows are in LDS; per chunk: barrier (weights landed, operand visible, previous chunk's readers done) ->
+    // wave 7 requests the next chunk of the whole sequence -> waves 0..6 run the tasks.
     auto run_phase = [&](int l, int p, auto tasks) {
         const mb_phase ph = phase_of(l, p);
         for (int ck = 0; ck < ph.nck; ++ck) {
@@ -847,11 +1016,32 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                 if (ck == 0 && (p == 0 || p == 2 || p == 4)) request_ln(l, p);      // (the LayerNorm before this phase has been through: its parameters may go)
             } else {
                 const int Rc = min(ph.rc, ph.r - ck * ph.rc);
-                tasks(ph, slot0 + (size_t) par * slot_bytes, wg * ph.r + ck * ph.rc, Rc);
+                tasks(ph, slot0 + (size_t) par * slot_bytes, wg * ph.r + ck * ph.rc, Rc, ck * ph.rc);
             }
             par ^= 1;
         }
     };
+    // the products of a chunk whose rows are 8 lanes wide, three token rows per pass (either weight format); epi as mb_products
+    auto prod8 = [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, const float * scale_l, const unsigned char * xop, size_t opb, auto epi) {
+        const float * bias_l = (const float *) (slot + slot_bytes - 512);
+        if constexpr (Q) mb_products_q<3>(slot, ph.soff, Rc, row_base, ph.N, bias_l, scale_l, xop, opb, ph.K, B, wave, lane, epi);
+        else mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, scale_l, (const wa_f16 *) xop, (int) (opb >> 1), ph.K, B, wave, lane, epi);
+    };
+    // gathered attention outputs / MLP activations -> operand rows in `xin`: packed F16 pairs, or - quantised - blocks of 9 granules (8 quads + scale)
+    auto gather_rows = [&](gu64 * edge, int len, unsigned code) {
+        if constexpr (Q) {
+            const int nb = len >> 5;
+            mb_gather<8>(c, edge, B, 9 * nb, RG, tid, lane, [&](int b, int j, unsigned v) {
+                const int blk = j / 9, kq = j - 9 * blk;
+                unsigned char * op = xin + (size_t) b * (len == d ? opB : op4);
+                if (kq < 8) mq_quads(op, nb, kq)[blk] = v; else mq_scales(op, nb)[blk] = __uint_as_float(v); }, code);
+        } else {
+            const size_t opb = len == d ? (size_t) d4 * 2 : op4;          // (F16: the d-long rows keep the 4d pitch)
+            if (len == d) mb_gather<8>(c, edge, B, len >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) (xin + (size_t) b * opb))[j] = v; }, code);
+            else          mb_gather<16>(c, edge, B, len >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) (xin + (size_t) b * opb))[j] = v; }, code);
+        }
+    };
+    const size_t opD = Q ? opB : (size_t) d4 * 2;      // pitch of the d-long operand rows in `xin`
 
     if (wave == MB_NW - 1 && L > 0) request(0, 0, 0, 0);
     const int twg = A->dbg ? ((const GAS int *) A->dbg)[4095] : 0;          // (trace: the workgroup that stamps)
@@ -861,13 +1051,12 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         MB_T(0);
         // ---------------- P1: LayerNorm + q|k|v ----------------
-        if (wave < B) mb_ln_row<NP>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, l == 0 ? Y.ln1_w : nullptr, l == 0 ? Y.ln1_b : nullptr,
-                                    wave, lane, xinB + (size_t) wave * d, xres + wave * 8, row_d, r_d, 100u + l);
+        if (wave < B) mb_ln_row<NP, Q>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, l == 0 ? Y.ln1_w : nullptr, l == 0 ? Y.ln1_b : nullptr,
+                                       wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), xres + wave * 8, row_d, r_d, 100u + l);
         MB_T(1);
-        run_phase(l, 0, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+        run_phase(l, 0, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
             gu64 * eq = mb_edge(A, l, E_QKV);
-            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), (const float *) (slot + slot_bytes - 256), xinB, d, ph.K, B, wave, lane,
-                              [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float scale) {
+            prod8(ph, slot, row_base, Rc, (const float *) (slot + slot_bytes - 256), xinB, opB, [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float scale) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int b = __builtin_amdgcn_readfirstlane(b0 + j < b1 ? b0 + j : b1 - 1);      // (wave-uniform: the row record comes by scalar loads)
@@ -887,38 +1076,33 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         });
         MB_T(2);
         // ---------------- P2: self-attention ----------------
-        for (int u = wg; u < B * H; u += nwg) mb_unit_self(A, c, area, l, u / H, u % H, tid);
+        for (int u = wg; u < B * H; u += nwg) mb_unit_self<Q>(A, c, area, l, u / H, u % H, tid);
         MB_T(3);
         // ---------------- P3: out-projection + residual ----------------
-        mb_gather<8>(c, mb_edge(A, l, E_AO), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 200u + l);
-        auto resid_tasks = [&](int e_out) {
-            return [&, e_out](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
-                gu64 * ex = mb_edge(A, l, e_out);
-                mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xin, d4, ph.K, B, wave, lane,
-                                  [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
+        gather_rows(mb_edge(A, l, E_AO), d, 200u + l);
+        auto resid_epi = [&](gu64 * ex) {
+            return [&, ex](auto & res, int b0, int b1, int n, bool has, float bias, float) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int b = b0 + j;
-                        if (has && b < b1) {
-                            const float v = res[j] + bias;
-                            const float xn = v + xres[b * 8 + (n - row_d)];
-                            gr_store(ex + (size_t) b * RG + n, seq, __float_as_uint(xn));
-                            xres[b * 8 + (n - row_d)] = xn;
-                        }
+                for (int j = 0; j < (int) (sizeof(res) / sizeof(float)); ++j) {
+                    const int b = b0 + j;
+                    if (has && b < b1) {
+                        const float v = res[j] + bias;
+                        const float xn = v + xres[b * 8 + (n - row_d)];
+                        gr_store(ex + (size_t) b * RG + n, seq, __float_as_uint(xn));
+                        xres[b * 8 + (n - row_d)] = xn;
                     }
-                });
+                }
             };
         };
         MB_T(4);
-        run_phase(l, 1, resid_tasks(E_X1));
+        run_phase(l, 1, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) { prod8(ph, slot, row_base, Rc, nullptr, xin, opD, resid_epi(mb_edge(A, l, E_X1))); });
         MB_T(5);
         // ---------------- P4: LayerNorm + cross query ----------------
-        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X1) + (size_t) wave * RG, lnp, nullptr, nullptr, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 300u + l);
+        if (wave < B) mb_ln_row<NP, Q>(A, c, mb_edge(A, l, E_X1) + (size_t) wave * RG, lnp, nullptr, nullptr, wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 300u + l);
         MB_T(6);
-        run_phase(l, 2, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+        run_phase(l, 2, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
             gu64 * eq = mb_edge(A, l, E_QC);
-            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xinB, d, ph.K, B, wave, lane,
-                              [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
+            prod8(ph, slot, row_base, Rc, nullptr, xinB, opB, [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int b = b0 + j;
@@ -934,22 +1118,21 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
             const int bh = u >> 2;
             mb_cross_regs CR;       // (asked for here: earlier - across the cross-query products - the 72 registers cost those products 2 us and won 0.8)
             mb_cross_load(A, l, bh / H, bh % H, u & 3, tid, CR);
-            mb_unit_cross(A, c, area, l, bh / H, bh % H, u & 3, tid, tw, CR);
+            mb_unit_cross<Q>(A, c, area, l, bh / H, bh % H, u & 3, tid, tw, CR);
         }
         MB_T(8);
         // ---------------- P6: out-projection + residual ----------------
-        mb_gather<8>(c, mb_edge(A, l, E_AO2), B, d >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 400u + l);
+        gather_rows(mb_edge(A, l, E_AO2), d, 400u + l);
         MB_T(9);
-        run_phase(l, 3, resid_tasks(E_X2));
+        run_phase(l, 3, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) { prod8(ph, slot, row_base, Rc, nullptr, xin, opD, resid_epi(mb_edge(A, l, E_X2))); });
         MB_T(10);
         // ---------------- P7: LayerNorm + FC1 + GELU ----------------
-        if (wave < B) mb_ln_row<NP>(A, c, mb_edge(A, l, E_X2) + (size_t) wave * RG, lnp, nullptr, nullptr, wave, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 500u + l);
+        if (wave < B) mb_ln_row<NP, Q>(A, c, mb_edge(A, l, E_X2) + (size_t) wave * RG, lnp, nullptr, nullptr, wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 500u + l);
         MB_T(11);
-        run_phase(l, 4, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
+        run_phase(l, 4, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int ck_row) {
             gu64 * eh = mb_edge(A, l, E_HF);
             const GAS wa_f16 * gelu = (const GAS wa_f16 *) A->gelu;
-            mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xinB, d, ph.K, B, wave, lane,
-                              [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
+            prod8(ph, slot, row_base, Rc, nullptr, xinB, opB, [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
                 float tv[3];                                           // wa_gelu (vec.h:571-585) through the F16 table: the look-ups of the token rows together
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { res[j] = res[j] + bias; tv[j] = h2f(gelu[has ? f2h(res[j]) : 0]); }
@@ -959,30 +1142,33 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                     const float v = res[j];
                     float gl = v;
                     if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = tv[j];
-                    const unsigned pk = mb_pack_h2((unsigned) f2h(gl));
-                    if (has && b < b1 && (lane & 15) == 0) gr_store(eh + (size_t) b * RG + (n >> 1), seq, pk);
-                }
-            });
-        });
-        MB_T(12);
-        // ---------------- P8: FC2 + residual ----------------
-        mb_gather<16>(c, mb_edge(A, l, E_HF), B, d4 >> 1, RG, tid, lane, [&](int b, int j, unsigned v) { ((unsigned *) xin)[(size_t) b * (d4 >> 1) + j] = v; }, 600u + l);
-        MB_T(13);
-        run_phase(l, 5, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc) {
-            gu64 * ex = mb_edge(A, l, E_X3);
-            mb_products<16, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, (const float *) (slot + slot_bytes - 512), nullptr, xin, d4, ph.K, B, wave, lane,
-                               [&](float (&res)[2], int b0, int b1, int n, bool has, float bias, float) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int b = b0 + j;
-                    if (has && b < b1) {
-                        const float v = res[j] + bias;
-                        const float xn = v + xres[b * 8 + (n - row_d)];
-                        gr_store(ex + (size_t) b * RG + n, seq, __float_as_uint(xn));
-                        xres[b * 8 + (n - row_d)] = xn;
+                    if constexpr (Q) { if (has && b < b1) fc1x[b * 32 + (n - wg * 32)] = gl; }      // F32: quantised below, once the block's 32 rows are through
+                    else {
+                        const unsigned pk = mb_pack_h2((unsigned) f2h(gl));
+                        if (has && b < b1 && (lane & 15) == 0) gr_store(eh + (size_t) b * RG + (n >> 1), seq, pk);
                     }
                 }
             });
+            (void) ck_row;
+        });
+        if constexpr (Q) {      // this workgroup's block of every token row: quantize_row_q8_0, published as 9 granules (wave b: row b)
+            mb_barrier();
+            if (wave < B && 32 * wg < d4) {
+                float dq;
+                const unsigned w = mq_quant32(fc1x[wave * 32 + (lane & 31)], dq);
+                gu64 * eb = mb_edge(A, l, E_HF) + (size_t) wave * RG + (size_t) wg * 9;
+                if (lane < 32 && (lane & 3) == 0) gr_store(eb + (lane >> 2), seq, w);
+                if (lane == 0) gr_store(eb + 8, seq, __float_as_uint(dq));
+            }
+        }
+        MB_T(12);
+        // ---------------- P8: FC2 + residual ----------------
+        gather_rows(mb_edge(A, l, E_HF), d4, 600u + l);
+        MB_T(13);
+        run_phase(l, 5, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
+            const float * bias_l = (const float *) (slot + slot_bytes - 512);
+            if constexpr (Q) mb_products_q<2>(slot, ph.soff, Rc, row_base, ph.N, bias_l, nullptr, xin, op4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
+            else mb_products<16, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, nullptr, (const wa_f16 *) xin, d4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
         });
     }
     { const int l = L; MB_T(0); }
@@ -990,36 +1176,58 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     const int n_out = A->n_out;
     if (wave < n_out) {
         const int br = A->out_row[wave];
-        mb_ln_row<NP>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, lnp, L > 0 ? nullptr : A->lnf_w, L > 0 ? nullptr : A->lnf_b, br, lane, xinB + (size_t) wave * d, nullptr, 0, 0, 3000u);
+        mb_ln_row<NP, Q>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, lnp, L > 0 ? nullptr : A->lnf_w, L > 0 ? nullptr : A->lnf_b, br, lane,
+                         (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 3000u);
     }
     mb_barrier();
-    if (n_out <= 2) mb_logits<2>(A, xinB, n_out, lane, wave); else if (n_out <= 4) mb_logits<4>(A, xinB, n_out, lane, wave);
-    else if (n_out <= 5) mb_logits<5>(A, xinB, n_out, lane, wave); else mb_logits<8>(A, xinB, n_out, lane, wave);
+    if constexpr (Q) {
+        if (n_out <= 2) mb_logits_q<2>(A, xinB, opB, n_out, lane, wave); else if (n_out <= 4) mb_logits_q<4>(A, xinB, opB, n_out, lane, wave);
+        else if (n_out <= 5) mb_logits_q<5>(A, xinB, opB, n_out, lane, wave); else mb_logits_q<8>(A, xinB, opB, n_out, lane, wave);
+    } else {
+        if (n_out <= 2) mb_logits<2>(A, (const wa_f16 *) xinB, n_out, lane, wave); else if (n_out <= 4) mb_logits<4>(A, (const wa_f16 *) xinB, n_out, lane, wave);
+        else if (n_out <= 5) mb_logits<5>(A, (const wa_f16 *) xinB, n_out, lane, wave); else mb_logits<8>(A, (const wa_f16 *) xinB, n_out, lane, wave);
+    }
     { const int l = L; MB_T(1); }
     if (wg == 0 && tid == 0) ((GAS unsigned *) A->status)[1] = seq;       // this launch ran (the host accepts a step only with its own number here)
 }
 
 __global__ __launch_bounds__(MB_THREADS) void k_decode_rows(const wa_rows_args A) {
     const mb_kargs Ap = (mb_kargs) __builtin_amdgcn_kernarg_segment_ptr();
-    if (A.d <= 768) mb_body<12>(Ap); else if (A.d <= 1024) mb_body<16>(Ap); else mb_body<20>(Ap);
+    if (A.d <= 768) mb_body<12, false>(Ap); else if (A.d <= 1024) mb_body<16, false>(Ap); else mb_body<20, false>(Ap);
+}
+// the same step for a quantised model (Q5_0 / Q8_0 files): a kernel of its own, so that the F16 kernel's code and registers stay as they are
+__global__ __launch_bounds__(MB_THREADS) void k_decode_rows_q(const wa_rows_args A) {
+    const mb_kargs Ap = (mb_kargs) __builtin_amdgcn_kernarg_segment_ptr();
+    if (A.d <= 768) mb_body<12, true>(Ap); else if (A.d <= 1024) mb_body<16, true>(Ap); else mb_body<20, true>(Ap);
 }
 
-size_t wa_rows_lds_bytes(int d, int B, int n_wg, int * slot_bytes) {
+size_t wa_rows_lds_bytes(int d, int B, int n_wg, int quant, int * slot_bytes) {
     if (B < 1 || B > WA_ROWS_MAX || d < 64 || d > WA_MEGA_MAX_D || (d & 127) != 0 || n_wg < 1) return 0;
-    const size_t xinB_bytes = ((size_t) B * d * 2 + 255) & ~(size_t) 255;
-    size_t area = (size_t) B * 4 * d * 2;
+    const size_t opB = quant ? mq_row_bytes(d >> 5) : (size_t) d * 2, op4 = quant ? mq_row_bytes((4 * d) >> 5) : (size_t) 4 * d * 2;
+    const size_t xinB_bytes = ((size_t) B * opB + 255) & ~(size_t) 255;
+    size_t area = (size_t) B * op4;
     if (area < MB_ATT_BYTES) area = MB_ATT_BYTES;
     area = (area + 255) & ~(size_t) 255;
-    const size_t fixed = 256 + 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023) + xinB_bytes + area;
+    const size_t fixed = 1280 + 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023) + xinB_bytes + area;
     auto rpw = [&](int N) { const int r = (N + n_wg - 1) / n_wg; return (r + 1) & ~1; };
     if (rpw(d) > 8) return 0;                       // (xres holds 8 residual values per token row)
+    if (quant && (4 * d) / 32 > n_wg) return 0;     // (whole-block ownership of the first MLP product: one workgroup per block)
     // a slot holds at least one task group of every phase; the whole chunk of a phase when there is room (fewer barriers)
-    const size_t need_min = std::max((size_t) 8 * (2 * d + MB_PAD), (size_t) 4 * (8 * d + MB_PAD)) + 1024;      // (+ the KB of bias / scale behind the rows)
-    size_t want = 0;
-    want = std::max(want, (size_t) ((rpw(3 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
-    want = std::max(want, (size_t) ((rpw(4 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
-    want = std::max(want, (size_t) ((rpw(d) + 3) / 4 * 4) * (8 * d + MB_PAD));
-    want = ((want + 1023) & ~(size_t) 1023) + 1024;
+    size_t need_min, want = 0;
+    if (quant) {
+        auto rowb = [&](int K) { return (size_t) K + MB_PAD + (size_t) (K >> 3) + MB_PAD; };
+        need_min = 8 * rowb(4 * d) + 3072;
+        want = std::max(want, (size_t) ((rpw(3 * d) + 7) / 8 * 8) * rowb(d));
+        want = std::max(want, (size_t) 32 * rowb(d));
+        want = std::max(want, (size_t) ((rpw(d) + 7) / 8 * 8) * rowb(4 * d));
+        want = ((want + 1023) & ~(size_t) 1023) + 3072;
+    } else {
+        need_min = std::max((size_t) 8 * (2 * d + MB_PAD), (size_t) 4 * (8 * d + MB_PAD)) + 1024;      // (+ the KB of bias / scale behind the rows)
+        want = std::max(want, (size_t) ((rpw(3 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
+        want = std::max(want, (size_t) ((rpw(4 * d) + 7) / 8 * 8) * (2 * d + MB_PAD));
+        want = std::max(want, (size_t) ((rpw(d) + 3) / 4 * 4) * (8 * d + MB_PAD));
+        want = ((want + 1023) & ~(size_t) 1023) + 1024;
+    }
     const size_t total_max = 160 * 1024;
     if (fixed + 2 * (need_min + 1024) > total_max) return 0;
     size_t slot = std::min(want, (total_max - fixed) / 2);
@@ -1031,15 +1239,17 @@ size_t wa_rows_lds_bytes(int d, int B, int n_wg, int * slot_bytes) {
 
 bool wa_launch_decode_rows(hipStream_t s, const wa_rows_args & a, int n_wg) {
     int slot = 0;
-    const size_t lds = wa_rows_lds_bytes(a.d, a.B, n_wg, &slot);
-    if (lds == 0 || slot != a.slot_bytes || a.quant) return false;
+    const size_t lds = wa_rows_lds_bytes(a.d, a.B, n_wg, a.quant, &slot);
+    if (lds == 0 || slot != a.slot_bytes) return false;
     int dev = 0;
     (void) hipGetDevice(&dev);
     static bool attr_set[64] = {};
     if (!attr_set[dev & 63]) {
-        if (hipFuncSetAttribute((const void *) k_decode_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void *) k_decode_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *) k_decode_rows_q, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
         attr_set[dev & 63] = true;
     }
-    hipLaunchKernelGGL(k_decode_rows, dim3(n_wg), dim3(MB_THREADS), lds, s, a);
+    if (a.quant) hipLaunchKernelGGL(k_decode_rows_q, dim3(n_wg), dim3(MB_THREADS), lds, s, a);
+    else         hipLaunchKernelGGL(k_decode_rows, dim3(n_wg), dim3(MB_THREADS), lds, s, a);
     return hipGetLastError() == hipSuccess;
 }

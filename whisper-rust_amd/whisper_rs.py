@@ -308,8 +308,12 @@ class WhisperContext:
                                     lib: Optional[C.CDLL] = None) -> "WhisperContext":
         lib = lib or load_library()
         params = params or WhisperContextParameters(lib)
-        cbuf = C.create_string_buffer(buf, len(buf))
-        ptr = lib.whisper_init_from_buffer_with_params_no_state(C.cast(cbuf, C.c_void_p), len(buf), params.c)
+        if isinstance(buf, np.ndarray):      # parsed in place (the library copies nothing beyond the call, whisper.cpp:3684-3719)
+            arr = np.ascontiguousarray(buf, dtype=np.uint8)
+            ptr = lib.whisper_init_from_buffer_with_params_no_state(C.c_void_p(arr.ctypes.data), arr.size, params.c)
+        else:
+            cbuf = C.create_string_buffer(buf, len(buf))
+            ptr = lib.whisper_init_from_buffer_with_params_no_state(C.cast(cbuf, C.c_void_p), len(buf), params.c)
         if not ptr:
             raise WhisperError("InitError")
         ctx = cls(lib, ptr)
