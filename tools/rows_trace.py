@@ -32,6 +32,10 @@ cn = ["issue loads", "q arrived", "barrier", "scores", "max exch", "exp", "sum e
 ct = np.zeros(10)
 for l in range(L): ct += np.diff(t[l * 32 + 16:l * 32 + 27]) / 100.0
 print("cross unit (mean): " + "  ".join("%s>%s %.2f" % (cn[i], cn[i + 1], x) for i, x in enumerate(ct / L)))
+bw = np.zeros(4)
+for l in range(L):
+    bw += np.array([t[l*32+14]-t[l*32+4], t[l*32+27]-t[l*32+6], t[l*32+15]-t[l*32+11], t[l*32+28]-t[l*32+13]]) / 100.0
+print("wait at the barrier in front of the products (mean): out %.2f  cq %.2f  fc1 %.2f  fc2 %.2f" % tuple(bw / L))
 print("mean   : " + "  ".join("%s %.2f" % (n, x) for n, x in zip(names, tot / L)) + "   | %.1f us per layer" % (tot.sum() / L))
 print("final LayerNorm + logits: %.1f us;  whole step %.1f us" % ((t[L * 32 + 1] - t[L * 32]) / 100.0, (t[L * 32 + 1] - t[0]) / 100.0))
 

@@ -342,7 +342,22 @@ __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_ro
         bool same = true;
 #pragma unroll
         for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) same &= wa_mean_indifferent(xv[k], mean, mean_hi);
-        if (!__all(same)) { s = mb_seq_sum<NP>(xv, d, false, 0.0f); mean = (float) (s / (double) d); }
+        if (!__all(same)) {
+            // Third level: an F64 sum of F32 values whose set bits span few enough binary places is EXACT in every order - no addition ever
+            // rounds -, so the wave's sum IS the reference's.  Bits of an element: exponent e .. e - 23; of a partial sum of n <= 2048
+            // elements: at most emax + 11 .. emin - 23; exact while that fits the 53 bits of a double.  Only wider rows go in order.
+            int emax = 0, emin = 255;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int e = (int) ((__float_as_uint(xv[k]) >> 23) & 0xffu);
+                if (e != 0) { emax = max(emax, e); emin = min(emin, e); }       // (zeros - and the padding - add nothing; denormals: e = 0 is left out, they only widen the span if present)
+                else if ((__float_as_uint(xv[k]) & 0x7fffffu) != 0u) emin = 0;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { emax = max(emax, __shfl_xor(emax, o, WAVE)); emin = min(emin, __shfl_xor(emin, o, WAVE)); }
+            if (emax - emin + 24 + 12 <= 53) mean = (float) (s / (double) d);
+            else { s = mb_seq_sum<NP>(xv, d, false, 0.0f); mean = (float) (s / (double) d); }
+        }
     }
     double s2 = 0.0;
 #pragma unroll
@@ -795,12 +810,28 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
 // final LayerNorm + logits = token_embedding . x for every token row (whisper.cpp:2820-2835): every workgroup, every wave; the embedding
 // rows stream from HBM into registers (two buffers of 24 steps: the loads of the next piece fly during the current one)
 // -------------------------------------------------------------------------------------------------
+// the first piece of a wave's first embedding rows, asked for BEFORE the final LayerNorm waits for its row (piece 0 of mb_logits / mb_logits_q)
+__device__ __forceinline__ void mb_te_first(mb_kargs A, bool quant, unsigned (&buf)[48], int lane, int wave) {
+    const int d = A->d, ns = d >> 5, n_vocab = A->n_vocab, u = lane & 7;
+    const int row = ((int) blockIdx.x + (int) gridDim.x * wave) * 8 + (lane >> 3), rc = row < n_vocab ? row : 0;
+    if (!quant) {
+        const gch wrow = (gch) A->te + (size_t) rc * d + 4 * u;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) { const u32x2 t = *(const GAS u32x2 *) (wrow + (size_t) (k < ns ? k : ns - 1) * 32); buf[2 * k] = t.x; buf[2 * k + 1] = t.y; }
+    } else {
+        const GAS unsigned * wl = (const GAS unsigned *) A->te + ((size_t) rc * 8 + u) * ns;
+        const GAS unsigned * dl = (const GAS unsigned *) A->te_d + (size_t) rc * ns;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) { const int bc = k < ns ? k : ns - 1; buf[k] = wl[bc]; buf[24 + k] = dl[bc]; }
+    }
+}
+
 template <int BT>
-__device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /* rows of xs = logits rows */, int lane, int wave) {
+__device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /* rows of xs = logits rows */, int lane, int wave, unsigned (&pfa)[48]) {
     const int d = A->d, ns = d >> 5, nbat = (ns + 23) / 24, n_vocab = A->n_vocab;
     const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
     GAS float * logits = (GAS float *) A->logits;
-    unsigned pfa[48], pfb[48];
+    unsigned pfb[48];
     auto grp = [&](int j) { return wg + nwg * (wave + MB_NW * j); };
     int n_items = 0;
     for (int j = 0; grp(j) < NG; ++j) n_items += nbat;
@@ -853,7 +884,7 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
             }
         }
     };
-    if (n_items > 0) load(0, pfa);
+    // (piece 0 is on its way since before the final LayerNorm: mb_te_first)
     for (int it = 0; it < n_items; it += 2) {
         if (it + 1 < n_items) load(it + 1, pfb);
         one(it, pfa);
@@ -866,11 +897,11 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
 // the same for a quantised token embedding: a row = 8 lanes x (quads [nb], F32 block scales [nb]) streamed in pieces of 24 blocks; the token
 // rows' final LayerNorm outputs sit in `xop` quantised (mb_ln_row<.., true>)
 template <int BT>
-__device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xop, size_t op_bytes, int B, int lane, int wave) {
+__device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xop, size_t op_bytes, int B, int lane, int wave, unsigned (&pfa)[48]) {
     const int d = A->d, nb = d >> 5, nbat = (nb + 23) / 24, n_vocab = A->n_vocab;
     const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
     GAS float * logits = (GAS float *) A->logits;
-    unsigned pfa[48], pfb[48];
+    unsigned pfb[48];
     auto grp = [&](int j) { return wg + nwg * (wave + MB_NW * j); };
     int n_items = 0;
     for (int j = 0; grp(j) < NG; ++j) n_items += nbat;
@@ -910,7 +941,7 @@ __device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xo
             }
         }
     };
-    if (n_items > 0) load(0, pfa);
+    // (piece 0 is on its way since before the final LayerNorm: mb_te_first)
     for (int it = 0; it < n_items; it += 2) {
         if (it + 1 < n_items) load(it + 1, pfb);
         one(it, pfa);
@@ -1002,6 +1033,8 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         else             { w = A->lnf_w; b_ = A->lnf_b; }
         mb_dma_vec(w, d, lnp, lane); mb_dma_vec(b_, d, lnp + ((d + 255) & ~255), lane);
     };
+    const int twg = A->dbg ? ((const GAS int *) A->dbg)[4095] : 0;          // (trace: the workgroup that stamps)
+    const bool tw = wg == twg && tid == 0;
     int par = 0;                 // parity of the chunk the NEXT product phase reads
     // One product phase: the operand rows are in LDS; per chunk: barrier (weights landed, operand visible, previous chunk's readers done) ->
     // wave 7 requests the next chunk of the whole sequence -> waves 0..6 run the tasks.
@@ -1009,6 +1042,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         const mb_phase ph = phase_of(l, p);
         for (int ck = 0; ck < ph.nck; ++ck) {
             mb_barrier_w(wave);
+            if (p == 1) mb_trace(A, tw, l * 32 + 14); else if (p == 4) mb_trace(A, tw, l * 32 + 15); else if (p == 2) mb_trace(A, tw, l * 32 + 27); else if (p == 5) mb_trace(A, tw, l * 32 + 28);
             if (wave == MB_NW - 1) {
                 int nl_ = l, np_ = p, nc_ = ck + 1;
                 if (nc_ >= ph.nck) { nc_ = 0; np_ = p + 1; if (np_ >= 6) { np_ = 0; nl_ = l + 1; } }
@@ -1022,10 +1056,21 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         }
     };
     // the products of a chunk whose rows are 8 lanes wide, three token rows per pass (either weight format); epi as mb_products
+    // Token rows per task: a phase's tasks = (groups of 8 weight rows) x (sub-batches of the token rows) run on the seven computing waves at once, so the
+    // sub-batches are as narrow as still gives <= 7 tasks (one octet of rows: one token row per task up to B = 7; two octets: two per task up to B = 6).
     auto prod8 = [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, const float * scale_l, const unsigned char * xop, size_t opb, auto epi) {
         const float * bias_l = (const float *) (slot + slot_bytes - 512);
-        if constexpr (Q) mb_products_q<3>(slot, ph.soff, Rc, row_base, ph.N, bias_l, scale_l, xop, opb, ph.K, B, wave, lane, epi);
-        else mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, scale_l, (const wa_f16 *) xop, (int) (opb >> 1), ph.K, B, wave, lane, epi);
+        const int groups = (Rc + 7) >> 3;
+        const int bc = groups * B <= MB_NCW ? 1 : groups * ((B + 1) >> 1) <= MB_NCW ? 2 : 3;
+        if constexpr (Q) {
+            if (bc == 1)      mb_products_q<1>(slot, ph.soff, Rc, row_base, ph.N, bias_l, scale_l, xop, opb, ph.K, B, wave, lane, epi);
+            else if (bc == 2) mb_products_q<2>(slot, ph.soff, Rc, row_base, ph.N, bias_l, scale_l, xop, opb, ph.K, B, wave, lane, epi);
+            else              mb_products_q<3>(slot, ph.soff, Rc, row_base, ph.N, bias_l, scale_l, xop, opb, ph.K, B, wave, lane, epi);
+        } else {
+            if (bc == 1)      mb_products<8, 1>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, scale_l, (const wa_f16 *) xop, (int) (opb >> 1), ph.K, B, wave, lane, epi);
+            else if (bc == 2) mb_products<8, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, scale_l, (const wa_f16 *) xop, (int) (opb >> 1), ph.K, B, wave, lane, epi);
+            else              mb_products<8, 3>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, scale_l, (const wa_f16 *) xop, (int) (opb >> 1), ph.K, B, wave, lane, epi);
+        }
     };
     // gathered attention outputs / MLP activations -> operand rows in `xin`: packed F16 pairs, or - quantised - blocks of 9 granules (8 quads + scale)
     auto gather_rows = [&](gu64 * edge, int len, unsigned code) {
@@ -1044,8 +1089,6 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     const size_t opD = Q ? opB : (size_t) d4 * 2;      // pitch of the d-long operand rows in `xin`
 
     if (wave == MB_NW - 1 && L > 0) request(0, 0, 0, 0);
-    const int twg = A->dbg ? ((const GAS int *) A->dbg)[4095] : 0;          // (trace: the workgroup that stamps)
-    const bool tw = wg == twg && tid == 0;
 #define MB_T(k) do { mb_trace(A, tw, l * 32 + (k)); mb_trace(A, tid == 0 && l == MB_TRACE_LAYER, 8192 + wg * 16 + (k)); } while (0)      /* every workgroup at ONE layer */
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
@@ -1056,9 +1099,9 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_T(1);
         run_phase(l, 0, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
             gu64 * eq = mb_edge(A, l, E_QKV);
-            prod8(ph, slot, row_base, Rc, (const float *) (slot + slot_bytes - 256), xinB, opB, [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float scale) {
+            prod8(ph, slot, row_base, Rc, (const float *) (slot + slot_bytes - 256), xinB, opB, [&](auto & res, int b0, int b1, int n, bool has, float bias, float scale) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < (int) (sizeof(res) / sizeof(float)); ++j) {
                     const int b = __builtin_amdgcn_readfirstlane(b0 + j < b1 ? b0 + j : b1 - 1);      // (wave-uniform: the row record comes by scalar loads)
                     float v = res[j] + bias;
                     v = v * scale;
@@ -1102,9 +1145,9 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_T(6);
         run_phase(l, 2, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
             gu64 * eq = mb_edge(A, l, E_QC);
-            prod8(ph, slot, row_base, Rc, nullptr, xinB, opB, [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
+            prod8(ph, slot, row_base, Rc, nullptr, xinB, opB, [&](auto & res, int b0, int b1, int n, bool has, float bias, float) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < (int) (sizeof(res) / sizeof(float)); ++j) {
                     const int b = b0 + j;
                     const float v = res[j] + bias;
                     const unsigned pk = mb_pack_h2((unsigned) f2h(v));
@@ -1132,12 +1175,13 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         run_phase(l, 4, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int ck_row) {
             gu64 * eh = mb_edge(A, l, E_HF);
             const GAS wa_f16 * gelu = (const GAS wa_f16 *) A->gelu;
-            prod8(ph, slot, row_base, Rc, nullptr, xinB, opB, [&](float (&res)[3], int b0, int b1, int n, bool has, float bias, float) {
-                float tv[3];                                           // wa_gelu (vec.h:571-585) through the F16 table: the look-ups of the token rows together
+            prod8(ph, slot, row_base, Rc, nullptr, xinB, opB, [&](auto & res, int b0, int b1, int n, bool has, float bias, float) {
+                constexpr int NB_ = (int) (sizeof(res) / sizeof(float));
+                float tv[NB_];                                         // wa_gelu (vec.h:571-585) through the F16 table: the look-ups of the token rows together
 #pragma unroll
-                for (int j = 0; j < 3; ++j) { res[j] = res[j] + bias; tv[j] = h2f(gelu[has ? f2h(res[j]) : 0]); }
+                for (int j = 0; j < NB_; ++j) { res[j] = res[j] + bias; tv[j] = h2f(gelu[has ? f2h(res[j]) : 0]); }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < NB_; ++j) {
                     const int b = b0 + j;
                     const float v = res[j];
                     float gl = v;
@@ -1167,13 +1211,21 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_T(13);
         run_phase(l, 5, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
             const float * bias_l = (const float *) (slot + slot_bytes - 512);
-            if constexpr (Q) mb_products_q<2>(slot, ph.soff, Rc, row_base, ph.N, bias_l, nullptr, xin, op4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
-            else mb_products<16, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, nullptr, (const wa_f16 *) xin, d4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
+            const int groups = (Rc + (Q ? 7 : 3)) / (Q ? 8 : 4);
+            if constexpr (Q) {
+                if (groups * B <= MB_NCW) mb_products_q<1>(slot, ph.soff, Rc, row_base, ph.N, bias_l, nullptr, xin, op4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
+                else                      mb_products_q<2>(slot, ph.soff, Rc, row_base, ph.N, bias_l, nullptr, xin, op4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
+            } else {
+                if (groups * B <= MB_NCW) mb_products<16, 1>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, nullptr, (const wa_f16 *) xin, d4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
+                else                      mb_products<16, 2>(slot, 2 * ph.K + MB_PAD, Rc, row_base, ph.N, bias_l, nullptr, (const wa_f16 *) xin, d4, ph.K, B, wave, lane, resid_epi(mb_edge(A, l, E_X3)));
+            }
         });
     }
     { const int l = L; MB_T(0); }
     // ---------------- final LayerNorm + logits (of the token rows that want them) ----------------
     const int n_out = A->n_out;
+    unsigned pf0[48];
+    mb_te_first(A, Q, pf0, lane, wave);
     if (wave < n_out) {
         const int br = A->out_row[wave];
         mb_ln_row<NP, Q>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, lnp, L > 0 ? nullptr : A->lnf_w, L > 0 ? nullptr : A->lnf_b, br, lane,
@@ -1181,11 +1233,11 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     }
     mb_barrier();
     if constexpr (Q) {
-        if (n_out <= 2) mb_logits_q<2>(A, xinB, opB, n_out, lane, wave); else if (n_out <= 4) mb_logits_q<4>(A, xinB, opB, n_out, lane, wave);
-        else if (n_out <= 5) mb_logits_q<5>(A, xinB, opB, n_out, lane, wave); else mb_logits_q<8>(A, xinB, opB, n_out, lane, wave);
+        if (n_out <= 2) mb_logits_q<2>(A, xinB, opB, n_out, lane, wave, pf0); else if (n_out <= 4) mb_logits_q<4>(A, xinB, opB, n_out, lane, wave, pf0);
+        else if (n_out <= 5) mb_logits_q<5>(A, xinB, opB, n_out, lane, wave, pf0); else mb_logits_q<8>(A, xinB, opB, n_out, lane, wave, pf0);
     } else {
-        if (n_out <= 2) mb_logits<2>(A, (const wa_f16 *) xinB, n_out, lane, wave); else if (n_out <= 4) mb_logits<4>(A, (const wa_f16 *) xinB, n_out, lane, wave);
-        else if (n_out <= 5) mb_logits<5>(A, (const wa_f16 *) xinB, n_out, lane, wave); else mb_logits<8>(A, (const wa_f16 *) xinB, n_out, lane, wave);
+        if (n_out <= 2) mb_logits<2>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0); else if (n_out <= 4) mb_logits<4>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0);
+        else if (n_out <= 5) mb_logits<5>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0); else mb_logits<8>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0);
     }
     { const int l = L; MB_T(1); }
     if (wg == 0 && tid == 0) ((GAS unsigned *) A->status)[1] = seq;       // this launch ran (the host accepts a step only with its own number here)
