@@ -334,7 +334,7 @@ def test_one_launch_decode_step_equals_launch_sequence(wrs, amd_lib, name, n_tok
     ref.free(); meg.free(); ctx.free()
 
 
-@pytest.mark.parametrize("name,n_tok", [("small", 16), ("m1024", 12), ("w1280", 8), ("small:q5_0", 16)])
+@pytest.mark.parametrize("name,n_tok", [("small", 16), ("m1024", 12), ("w1280", 8), ("small:q5_0", 16), ("w1280:q5_0", 8), ("s128:q8_0", 12)])
 def test_one_launch_step_under_stalls(wrs, name, n_tok, monkeypatch):
     """The same comparison on the test build whose product waves stall at random for ~25 us (libwhisper_chaos.so: wa_mega.hip with
     -DMG_CHAOS): the rest of the workgroup and of the grid then runs far ahead of the stalled wave, so anything in LDS that relied on
@@ -364,6 +364,61 @@ def test_one_launch_step_under_stalls(wrs, name, n_tok, monkeypatch):
         tok = int(np.argmax(a[:50000]))
     assert lib.whisper_amd_mega_enabled(meg.ptr) == 1, "the one-launch step gave up under the stalls"
     ref.free(); meg.free(); ctx.free()
+
+
+@pytest.mark.parametrize("name", ["small", "m1024", "s128:q5_0"])
+def test_several_rows_step_under_stalls(wrs, name, monkeypatch):
+    """The several-rows one-launch step (wa_rows.hip) on the stalled test build (-DMB_CHAOS: waves and whole workgroups sleep ~25 us at random in
+    front of products, attention units and gathers): batches of 2 / 5 / 8 tokens - causal masks, cells written by the launch itself - give the
+    logits of the launch sequence, and every pass is served by the one-launch form."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "whisper-rust_amd", "libwhisper_chaos.so")
+    assert os.path.exists(path), "libwhisper_chaos.so missing: make -C whisper-rust_amd libwhisper_chaos.so (__graft_entry__.build() does)"
+    lib = wrs.load_library(path)
+    wrs.set_log_callback(lib, lambda lvl, txt: sys.stderr.write(txt) if lvl >= 3 else None)
+    mp = wsynth.quant_model_path(*name.split(":")) if ":" in name else wsynth.model_path(name)
+    ctx = wrs.WhisperContext.new_with_params(mp, wrs.WhisperContextParameters(lib), lib=lib)
+    monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "1"); ref = ctx.create_state()
+    monkeypatch.setenv("WHISPER_AMD_NO_MEGA", "0"); row = ctx.create_state()
+    if lib.whisper_amd_rows_enabled(row.ptr) != 1:
+        pytest.skip("several-rows step not available")
+    pcm = wsynth.synth_audio(480000, 2)
+    for st in (ref, row):
+        st.pcm_to_mel(pcm); st.encode(0)
+    n_past = 0
+    for rnd in range(3):
+        for n in (3, 5, 8, 2):
+            batch = [1000 + 37 * (n_past + i) for i in range(n)]
+            ref.decode(batch, n_past); row.decode(batch, n_past)
+            a = ref.get_logits_last(n); b = row.get_logits_last(n)
+            assert digest(a) == digest(b), "batch of %d at n_past %d: max|d| = %g" % (n, n_past, float(np.abs(a - b).max()))
+            n_past += n
+    served, back = row.rows_stats()
+    assert served == 12 and back == 0, (served, back)
+    ref.free(); row.free(); ctx.free()
+
+
+def test_lockstep_group_survives_a_failed_pass(wrs, amd_lib, monkeypatch):
+    """A lock-step pass whose launch fails (forced through WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH) must not hand out the stale contents of the
+    staging buffer: every member then decodes alone, and each chunk's segments equal the goldens of the reference engine."""
+    import json
+    from conftest import GOLDEN
+    import gen_golden_r2 as gen
+    gold = json.load(open(os.path.join(GOLDEN, "r2_cases.json")))
+    # (the hook is read once per process: the chunks run in a child process that starts with it set; this process never sees it)
+    import subprocess
+    code = ("import sys, json; sys.path[:0] = [%r, %r]; import wsynth, whisper_rs as W, gen_golden_r2 as gen\n"
+            "lib = W.load_library(); W.set_log_callback(lib, None)\n"
+            "ctx = W.WhisperContext.new_with_params(wsynth.model_path('s128'), W.WhisperContextParameters(lib), lib=lib)\n"
+            "sts = [ctx.create_state() for _ in gen.BATCH_SEEDS]\n"
+            "W.full_batch(ctx, sts, W.FullParams(lib, 0, best_of=1, temperature_inc=0.0), [wsynth.synth_audio(480000, s) for s in gen.BATCH_SEEDS])\n"
+            "print(json.dumps([[dict(t0=s['t0'], t1=s['t1'], ids=s['ids']) for s in st.segments()] for st in sts]))\n"
+            % (os.path.join(os.path.dirname(GOLDEN), "..", "tools"), os.path.join(os.path.dirname(GOLDEN), "..", "whisper-rust_amd")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600, env=dict(os.environ, WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH="1"))
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-800:]
+    got = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    for g, s in zip(got, gen.BATCH_SEEDS):
+        want = [dict(t0=x["t0"], t1=x["t1"], ids=x["ids"]) for x in gold["s128"]["batch"]["seed%d" % s]]
+        assert g == want, s
 
 
 def test_full_transcription_under_stalls(wrs, monkeypatch):

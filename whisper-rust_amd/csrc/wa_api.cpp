@@ -323,6 +323,7 @@ struct whisper_state * whisper_init_state(struct whisper_context * ctx) {
 void whisper_free_state(struct whisper_state * st) { if (st) { wa_state_release(*st); delete st; } }
 void whisper_free(struct whisper_context * ctx) {
     if (!ctx) return;
+    wa_batcher_free_all(*ctx);
     whisper_free_state(ctx->state);
     wa_model_free(*ctx);
     delete ctx;

@@ -248,11 +248,19 @@ static void decode_launch_quant(whisper_context & ctx, whisper_state & st, int n
 // that do not need the slot (several tokens, masks, beams: the launch sequence) run concurrently on their own streams.
 static std::mutex & mega_slot(int device) { static std::mutex m[64]; return m[(unsigned) device & 63u]; }
 
+// a one-launch form gave up at a hand-off: pause it (the launch sequence serves meanwhile), try again later, give up for good after 8 time-outs
+static void one_launch_timeout(int & pause, int & timeouts, bool & enabled, const char * what, unsigned status) {
+    timeouts += 1;
+    if (timeouts > 8) { enabled = false; WA_WARN("%s: gave up at hand-off %u for the 9th time - using the launch sequence from now on\n", what, status); return; }
+    pause = 32 << std::min(timeouts, 6);
+    WA_WARN("%s: gave up at hand-off %u - the launch sequence serves the next %d decoder passes, then it is tried again\n", what, status, pause);
+}
+
 static bool mega_args(whisper_context & ctx, whisper_state & st, wa_mega_args & a, int token, int pos, int n_kv, int kv_head) {
     const auto & m = ctx.model;
     const auto & hp = m.hp;
     const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
-    if (!st.mega_enabled || n_kv > WA_MEGA_KV_ROOM || n_kv < 1 || kv_head < 0 || kv_head >= n_kv || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
+    if (!st.mega_enabled || st.mega_pause > 0 || n_kv > WA_MEGA_KV_ROOM || n_kv < 1 || kv_head < 0 || kv_head >= n_kv || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
     a.layers = (const wa_mega_layer *) m.d_mega_layers;
     a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
     a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu;
@@ -279,25 +287,21 @@ static int mega_step(whisper_context & ctx, whisper_state & st, int token, int p
     if (!mega_args(ctx, st, a, token, pos, n_kv, kv_head)) return 0;
     const int n_vocab = ctx.model.hp.n_vocab;
     hipStream_t s = st.stream;
-    unsigned status = 0;
+    unsigned status = 0, echo = 0;
     {
         std::lock_guard<std::mutex> lk(mega_slot(ctx.device));
-        wa_launch_decode_mega(s, a, std::min(ctx.model.n_cu, 256));
-        (void) hipMemcpyAsync(st.h_logits_pinned, st.d_mega_out, ((size_t) n_vocab + 1) * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (!wa_launch_decode_mega(s, a, std::min(ctx.model.n_cu, 256))) { st.mega_enabled = false; return 0; }
+        (void) hipMemcpyAsync(st.h_logits_pinned, st.d_mega_out, ((size_t) n_vocab + 3) * sizeof(float), hipMemcpyDeviceToHost, s);
         if (!WA_HIP_OK(hipStreamSynchronize(s))) { st.mega_enabled = false; return 0; }
         status = ((const unsigned *) st.h_logits_pinned)[n_vocab];
+        echo = ((const unsigned *) st.h_logits_pinned)[n_vocab + 2];
     }
-    if (status == WA_MEGA_REDO) {      // an uncertifiable soft-max sum (~1e-9 per soft-max): this token goes through the launch sequence
-        (void) hipMemsetAsync(st.d_mega_status, 0, sizeof(unsigned), s);
-        return 0;
-    }
-    if (status != 0) {     // a hand-off timed out (workgroups not co-resident?): fall back for good
-        WA_WARN("%s: one-launch decode step gave up at hand-off %u - using the launch sequence from now on\n", __func__, status);
-        (void) hipMemsetAsync(st.d_mega_status, 0, sizeof(unsigned), s);
-        st.mega_enabled = false;
-        return 0;
-    }
-    return 1;
+    if (status == 0 && echo == a.seq) return 1;
+    (void) hipMemsetAsync(st.d_mega_status, 0, sizeof(unsigned), s);
+    if (status == WA_MEGA_REDO) return 0;       // an uncertifiable soft-max sum (~1e-9 per soft-max): this token goes through the launch sequence
+    // a hand-off timed out (workgroups not co-resident?), or the launch never ran (no echo of its number): the logits are not this step's
+    one_launch_timeout(st.mega_pause, st.mega_timeouts, st.mega_enabled, "one-launch decode step", status);
+    return 0;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -310,6 +314,7 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
                      uint32_t kv_size, bool wait_slot) {
     const auto & m = ctx.model;
     const auto & hp = m.hp;
+    if (bst.rows_pause > 0) { bst.rows_pause -= 1; return 0; }
     if (B < 1 || B > WA_ROWS_MAX || n_out < 1 || n_out > B || !bst.rows_enabled || T < 1 || (T >> 5) > 47 || T > cross_tpad) return 0;
     for (int i = 0; i < B; ++i)
         if (rows[i].n_kv < 1 || rows[i].n_kv > WA_ROWS_MAXKV || rows[i].kv_head < 0 || rows[i].kv_head >= rows[i].n_kv) return 0;
@@ -348,8 +353,7 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
     bst.n_rows_fallback += 1;
     (void) hipMemsetAsync(bst.d_rows_status, 0, sizeof(unsigned), s);
     if (status == WA_MEGA_REDO) return 0;          // an uncertifiable soft-max sum (~1e-9 per soft-max): this pass goes through the launch sequence
-    WA_WARN("%s: the %d-row one-launch step gave up (status %u, launch %u / %u) - using the launch sequence from now on\n", __func__, B, status, echo, a.seq);
-    bst.rows_enabled = false;
+    one_launch_timeout(bst.rows_pause, bst.rows_timeouts, bst.rows_enabled, "several-rows one-launch step", status);
     return 0;
 }
 
@@ -363,7 +367,7 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
 // k & 1 and reads buffer (k - 1) & 1; at most launches k and k + 1 are in flight while the host works on logits k - 1...k.
 // -------------------------------------------------------------------------------------------------
 bool wa_spec_begin(whisper_context & ctx, whisper_state & st, const std::vector<uint32_t> & bits) {
-    if (!st.mega_enabled || bits.size() > (size_t) ctx.model.hp.n_vocab / 32 + 2) return false;
+    if (!st.mega_enabled || st.mega_pause > 0 || bits.size() > (size_t) ctx.model.hp.n_vocab / 32 + 2) return false;
     if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
     if (!st.copy_stream) {      // first use on this state
         for (int b = 0; b < 2; ++b) {
@@ -405,10 +409,11 @@ bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, i
     a.rec_in = st.d_mega_rec[b ^ 1]; a.rec_out = st.d_mega_rec[b];
     a.ps_in = st.d_mega_ps[b ^ 1];   a.ps_out = st.d_mega_ps[b];
     a.s_last = after.last; a.s_penult = after.penult; a.s_seek_delta = after.seek_delta; a.s_has_ts = after.has_ts;
-    wa_launch_decode_mega(st.stream, a, a.n_rec);
+    if (!wa_launch_decode_mega(st.stream, a, a.n_rec)) return false;
+    st.spec_seq[b] = a.seq;
     (void) hipEventRecord(st.ev_k[b], st.stream);
     (void) hipStreamWaitEvent(st.copy_stream, st.ev_k[b], 0);
-    (void) hipMemcpyAsync(st.h_spec[b], a.logits, ((size_t) ctx.model.hp.n_vocab + 2) * sizeof(float), hipMemcpyDeviceToHost, st.copy_stream);
+    (void) hipMemcpyAsync(st.h_spec[b], a.logits, ((size_t) ctx.model.hp.n_vocab + 3) * sizeof(float), hipMemcpyDeviceToHost, st.copy_stream);
     return WA_HIP_OK(hipEventRecord(st.ev_c[b], st.copy_stream));
 }
 
@@ -416,7 +421,8 @@ int wa_spec_wait(whisper_context & ctx, whisper_state & st, int k, int * token_u
     const int b = k & 1, n_vocab = ctx.model.hp.n_vocab;
     const int64_t t0 = wa_time_us();
     if (!WA_HIP_OK(hipEventSynchronize(st.ev_c[b]))) { st.mega_enabled = false; return -1; }
-    const unsigned status = ((const unsigned *) st.h_spec[b])[n_vocab];
+    unsigned status = ((const unsigned *) st.h_spec[b])[n_vocab];
+    if (status == 0 && ((const unsigned *) st.h_spec[b])[n_vocab + 2] != st.spec_seq[b]) status = 9999u;      // the launch never ran: not this step's logits
     if (token_used) *token_used = ((const int *) st.h_spec[b])[n_vocab + 1];
     st.t_decode_us += wa_time_us() - t0; st.n_decode++;
     if (status != 0) {
@@ -425,8 +431,7 @@ int wa_spec_wait(whisper_context & ctx, whisper_state & st, int k, int * token_u
         (void) hipMemsetAsync(st.d_mega_out2 + n_vocab, 0, sizeof(unsigned), st.stream);
         (void) hipStreamSynchronize(st.stream);
         if (status == WA_MEGA_REDO) return 1;
-        WA_WARN("%s: one-launch decode step gave up at hand-off %u - using the launch sequence from now on\n", __func__, status);
-        st.mega_enabled = false;
+        one_launch_timeout(st.mega_pause, st.mega_timeouts, st.mega_enabled, "one-launch decode step", status);
         return -1;
     }
     st.logits.resize(n_vocab);
@@ -464,22 +469,45 @@ struct wa_batcher {
     bool graphs_ok = true;
 };
 
+// Batchers (a private state - activations, granules, stream - and the captured graphs) are kept on the context between calls: building one
+// allocates a whole whisper_state, and its hipMalloc / hipFree calls synchronise the device under the other chunks' encoders.  wa_batcher_create
+// takes a free one (or makes one), wa_batcher_destroy hands it back; whisper_free releases them (wa_batcher_free_all).
+static std::mutex & batcher_cache_mutex() { static std::mutex m; return m; }
 wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
     if (ctx.model.n_loaded == 0 || n_members < 2) return nullptr;
-    auto * b = new wa_batcher();
+    wa_batcher * b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(batcher_cache_mutex());
+        if (!ctx.batcher_cache.empty()) { b = (wa_batcher *) ctx.batcher_cache.back(); ctx.batcher_cache.pop_back(); }
+    }
+    if (b) {
+        b->n_members = n_members; b->waiting.clear(); b->n_steps = b->n_rows = b->n_one_launch = 0;
+        return b;
+    }
+    b = new wa_batcher();
     b->ctx = &ctx; b->n_members = n_members;
     b->bst = whisper_init_state(&ctx);
     if (!b->bst || !WA_HIP_OK(hipHostMalloc((void **) &b->h_rowp, WA_MAX_DECODERS * sizeof(wa_rowptr))) ||
-        !WA_HIP_OK(hipMalloc((void **) &b->d_rowp, WA_MAX_DECODERS * sizeof(wa_rowptr)))) { wa_batcher_destroy(b); return nullptr; }
+        !WA_HIP_OK(hipMalloc((void **) &b->d_rowp, WA_MAX_DECODERS * sizeof(wa_rowptr)))) { wa_batcher_release(b); return nullptr; }
     return b;
 }
-void wa_batcher_destroy(wa_batcher * b) {
+void wa_batcher_release(wa_batcher * b) {
     if (!b) return;
     for (auto & g : b->graph) if (g) (void) hipGraphExecDestroy(g);
     if (b->bst) whisper_free_state(b->bst);
     if (b->h_rowp) (void) hipHostFree(b->h_rowp);
     if (b->d_rowp) (void) hipFree(b->d_rowp);
     delete b;
+}
+void wa_batcher_destroy(wa_batcher * b) {           // back to its context's cache
+    if (!b) return;
+    std::lock_guard<std::mutex> lk(batcher_cache_mutex());
+    b->ctx->batcher_cache.push_back(b);
+}
+void wa_batcher_free_all(whisper_context & ctx) {
+    std::vector<void *> all;
+    { std::lock_guard<std::mutex> lk(batcher_cache_mutex()); all.swap(ctx.batcher_cache); }
+    for (void * b : all) wa_batcher_release((wa_batcher *) b);
 }
 void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows, long * one_launch) { if (b) { *steps = b->n_steps; *rows = b->n_rows; if (one_launch) *one_launch = b->n_one_launch; } }
 
@@ -503,6 +531,9 @@ static void batcher_run(wa_batcher & b) {
     }
     const int B = (int) run.size();
     bool ok = WA_HIP_OK(hipSetDevice(ctx.device));
+    // (tests: a pass whose launch failed must not hand out the stale contents of the staging buffer - every member then decodes alone)
+    static const bool test_fail = getenv("WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH") != nullptr;
+    if (test_fail) ok = false;
     if (ok) {
         hipStream_t s = bs.stream;
         int32_t * h_tok = bs.h_stage_i32, * h_pos = h_tok + bs.dec_mpad, * h_rows = h_pos + bs.dec_mpad;
@@ -549,9 +580,6 @@ static void batcher_run(wa_batcher & b) {
         if (b.graph[B] && !no_graph) ok = WA_HIP_OK(hipGraphLaunch(b.graph[B], s)) && ok;
         else decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
         ok = hipGetLastError() == hipSuccess && ok;
-        // (tests: a pass whose launch failed must not hand out the stale contents of the staging buffer - every member then decodes alone)
-        static const bool test_fail = getenv("WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH") != nullptr;
-        if (test_fail) ok = false;
         (void) hipMemcpyAsync(bs.h_logits_pinned, bs.d_logits, (size_t) B * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
         ok = WA_HIP_OK(hipStreamSynchronize(s)) && ok;
         if (!ok) b.graphs_ok = false;
@@ -611,7 +639,6 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
         if (n_rows_req > WA_MAX_DECODERS) { WA_ERROR("%s: too many logits rows requested (%d)\n", __func__, n_rows_req); return false; }
     }
     auto & kv = st.kv_self;
-    if (kv.size > WA_ATT_MAXKV) { WA_ERROR("%s: %u KV cells exceed the attention kernels' limit (%d)\n", __func__, kv.size, WA_ATT_MAXKV); return false; }
     if (!wa_kv_find_slot(kv, batch)) return false;
     kv.n = std::min(kv.size, (uint32_t) std::max(1, wa_kv_cell_max(kv)));     // padding = 1 (whisper.cpp:2892-2893)
     const int n_kv = kv.n, kv_head = kv.head;
@@ -632,12 +659,6 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
         h_pos[i] = batch.pos[i];
         if (batch.logits[i]) h_rows[n_rows++] = i;
     }
-    if (n_rows > WA_MAX_DECODERS) { WA_ERROR("%s: too many logits rows requested (%d)\n", __func__, n_rows); return false; }
-    for (int i = 0; i < n_tokens; ++i)
-        if (h_tok[i] < 0 || h_tok[i] >= n_vocab || h_pos[i] < 0 || h_pos[i] >= hp.n_text_ctx) {
-            WA_ERROR("%s: token %d / position %d out of range\n", __func__, h_tok[i], h_pos[i]);
-            return false;
-        }
     if ((size_t) n_tokens * n_kv > st.h_mask_cap) { WA_ERROR("%s: mask overflow\n", __func__); return false; }
     int8_t * h_mask = st.h_stage_mask;
     for (int j = 0; j < n_tokens; ++j) {
@@ -651,7 +672,8 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     const bool steady = n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads;
     bool done = false, from_batcher = false;
     if (steady && st.batcher) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
-    if (!done && steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    if (!done && steady && st.mega_enabled && st.mega_pause > 0) st.mega_pause -= 1;      // (paused after a time-out: this pass takes the launch sequence)
+    else if (!done && steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && n_kv <= WA_ROWS_MAXKV) {
         // one token per live decoder (beam search, best_of, the bench's small batches): all rows in ONE launch (wa_rows.hip)
         if (need_mask) (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
@@ -737,9 +759,9 @@ extern "C" int whisper_amd_decode_step_probe(struct whisper_context * ctx, struc
         if (mega_args(*ctx, *st, a, h[0], n_past, n_past + 1, n_past)) {
             std::lock_guard<std::mutex> lk(mega_slot(ctx->device));
             const int n_wg = std::min(ctx->model.n_cu, 256);
-            wa_launch_decode_mega(s, a, n_wg);      // warm-up
+            (void) wa_launch_decode_mega(s, a, n_wg);      // warm-up
             (void) hipEventRecord(e0, s);
-            for (int i = 0; i < n_iters; ++i) { mega_args(*ctx, *st, a, h[0], n_past, n_past + 1, n_past); wa_launch_decode_mega(s, a, n_wg); }
+            for (int i = 0; i < n_iters; ++i) { mega_args(*ctx, *st, a, h[0], n_past, n_past + 1, n_past); (void) wa_launch_decode_mega(s, a, n_wg); }
             (void) hipEventRecord(e1, s);
             if (!WA_HIP_OK(hipEventSynchronize(e1))) return -1;
             float ms = 0.f;
@@ -802,7 +824,7 @@ extern "C" int whisper_amd_mega_debug(struct whisper_context * ctx, struct whisp
     std::lock_guard<std::mutex> lk(mega_slot(ctx->device));
     int n_wg = std::min(ctx->model.n_cu, 256);
     if (const char * e = getenv("WHISPER_AMD_MEGA_WG")) n_wg = std::max(2 * hp.n_text_head + 1, std::min(n_wg, atoi(e)));
-    wa_launch_decode_mega(st->stream, a, n_wg);
+    (void) wa_launch_decode_mega(st->stream, a, n_wg);
     if (!WA_HIP_OK(hipStreamSynchronize(st->stream))) return -3;
     if (a.dbg) { std::vector<float> h(n_dbg); (void) hipMemcpy(h.data(), d_dbg, n_dbg * 4, hipMemcpyDeviceToHost); FILE * f = fopen("gpurun_out/mega_dbg.bin", "wb"); if (f) { fwrite(h.data(), 4, n_dbg, f); fclose(f); } }
     if (granules_out)      // [layer][8][2d]: the first 2d granules of every edge (the device keeps 4d per edge)

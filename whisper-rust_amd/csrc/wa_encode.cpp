@@ -25,6 +25,8 @@ template <typename T> static void dev_free(T *& p) { if (p) { (void) hipFree(p);
 
 bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells) {
     const auto & hp = ctx.model.hp;
+    // refused once, where the cache is made (not per decode call): the attention kernels keep a launch's scores / probabilities in LDS
+    if (n_cells > WA_ATT_MAXKV) { WA_ERROR("%s: %d KV cells exceed the attention kernels' limit (%d)\n", __func__, n_cells, WA_ATT_MAXKV); return false; }
     if (st.dec_graph) { (void) hipGraphExecDestroy(st.dec_graph); st.dec_graph = nullptr; }
     dev_free(st.kv_self.k);
     dev_free(st.kv_self.v);
@@ -258,7 +260,7 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
     wa_launch_mel_window(s, st.d_mel, hp.n_mels, st.mel_n_len, mel_offset, 2 * T, st.d_melT, rows_total);
 
     // Two interchangeable implementations of every dense product:
-    //   exact (flash_attn == false): reference summation order on the VALU -> bit-identical to whisper.cpp CPU
+    //   exact (flash_attn == false): reference summation order on the F32 matrix cores -> bit-identical to whisper.cpp CPU
     //   fast  (flash_attn == true) : MFMA (v_mfma_f32_16x16x32_f16), same rounding points, different F32 order
     const bool exact = ctx.exact || m.wtype != 1;       // (quantised models: the conv stem stays F16 and runs in the reference order)
     auto gemm = [&](wa_epi_mode mode, const wa_f16 * A, int lda, const wa_f16 * W, int ldw, int M, int N, int K, const wa_epi & e) {

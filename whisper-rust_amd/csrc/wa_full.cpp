@@ -711,7 +711,7 @@ int runner::run(const float * samples, int n_samples) {
                 const auto & kvc = st->kv_self;
                 const bool seq_cells = wa_kv_cell_max(kvc) == P && P < (int) kvc.size && kvc.cells[P].pos < 0;
                 if (!(e && e[0] == '1') && p.strategy == WHISPER_SAMPLING_GREEDY && n_dec == 1 && t_cur < 1e-6f && !p.logits_filter_callback &&
-                    st->mega_enabled && !st->batcher && ctx->model.n_loaded > 0 && seq_cells)      // (a lock-step member: its steps go through the group's passes)
+                    st->mega_enabled && st->mega_pause == 0 && !st->batcher && ctx->model.n_loaded > 0 && seq_cells)      // (a lock-step member: its steps go through the group's passes)
                     ov.on = wa_spec_begin(*ctx, *st, suppress_bits());
             }
 

@@ -124,6 +124,7 @@ struct whisper_context {
     wa_vocab vocab;
     whisper_state * state = nullptr;      // default state (only for the non-_no_state constructors)
     std::string path_model;
+    std::vector<void *> batcher_cache;    // idle lock-step batchers (wa_decode.cpp), kept between whisper_amd_full_batch / whisper_full_parallel calls
     long batch_steps = 0, batch_rows = 0, batch_one_launch = 0; // the last whisper_amd_full_batch call: lock-step passes, the token rows they served, passes that were one launch
 };
 
@@ -252,6 +253,10 @@ struct whisper_state {
     unsigned * d_mega_status = nullptr;   // = d_mega_out + n_vocab
     unsigned mega_seq = 0;
     bool mega_enabled = false;
+    // a hand-off time-out (e.g. a co-tenant kernel held CUs: the step's workgroups were not all resident) pauses the one-launch forms for
+    // `*_pause` decoder passes, which take the launch sequence, and then tries again (doubling the pause each time; after 8 time-outs: off)
+    int mega_pause = 0, mega_timeouts = 0, rows_pause = 0, rows_timeouts = 0;
+    unsigned spec_seq[2] = { 0, 0 };               // launch numbers of the two launches in flight (their echo is checked on arrival)
     // host overlap (wa_decode.cpp wa_spec_*): the device predicts the next token and decodes it while the host still
     // applies the reference's sampling rules to the previous logits; two output / record / state buffers alternate
     float * d_mega_out2 = nullptr;                 // second logits + status + token buffer
@@ -319,7 +324,9 @@ void wa_spec_end   (whisper_context & ctx, whisper_state & st);
 struct wa_batcher;
 wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members);      // null: not applicable (quantised model, one chunk)
 void wa_batcher_leave(wa_batcher * b);
-void wa_batcher_destroy(wa_batcher * b);
+void wa_batcher_destroy(wa_batcher * b);          // hands the batcher back to its context's cache
+void wa_batcher_release(wa_batcher * b);          // frees it
+void wa_batcher_free_all(whisper_context & ctx);  // whisper_free
 void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows, long * one_launch = nullptr);
 bool wa_state_alloc(whisper_context & ctx, whisper_state & st);
 void wa_state_release(whisper_state & st);

@@ -32,7 +32,7 @@ struct wa_mega_args {
     int cross_tpad, T;
     unsigned long long * granules; int edge_stride;                            // [layer][8][edge_stride] hand-off granules
     unsigned long long * cross_gr;                                              // [layer][head][2048] exchange area of a head's four cross-attention workgroups
-    float * logits;                                                             // [n_vocab]
+    float * logits;                                                             // [n_vocab], then: status word, the token decoded (spec), the launch's sequence number once it has run
     unsigned * status;                                                          // 0 = ok; else code of the hand-off that timed out
     float * dbg;                                                                // optional [layer][head][2][1536]: cross-attention scores, probabilities
     // launch
@@ -87,5 +87,5 @@ WA_HD inline void mg_role_of(int n, int H, int b, int & role, int & idx) {
 }
 
 // n_wg workgroups of 512 threads, every one of them resident at once (n_wg <= number of CUs; 1 workgroup per CU)
-void   wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg);      // a.quant selects the quantised-weights form of the kernel
+bool   wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg);      // a.quant selects the quantised-weights form of the kernel; false: the launch failed
 size_t wa_mega_lds_bytes();

@@ -25,9 +25,9 @@ typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // (HIP's u32x4 class cannot be read through an address-space pointer)
 
-// The roles are separate (noinline) functions so that each gets the whole register file.  They read the launch arguments
-// from the kernel-argument segment (scalar loads: every field stays wave-uniform); the kernel hands them its address
-// (the intrinsic itself folds to null inside a callee) and the callee makes it provably uniform again.
+// The roles are inlined into the kernel (as separate functions they saved 112 callee-saved VGPRs per thread on entry: 58 MB of scratch
+// per launch).  They read the launch arguments from the kernel-argument segment (scalar loads: every field stays wave-uniform); the
+// kernel hands them its address and mg_uniform makes it provably uniform again.
 typedef const __attribute__((address_space(4))) wa_mega_args * mg_kargs;
 __device__ __forceinline__ mg_kargs mg_uniform(mg_kargs p) {
     const unsigned long long v = (unsigned long long) p;
@@ -38,7 +38,7 @@ __device__ __forceinline__ mg_kargs mg_uniform(mg_kargs p) {
 #define MG_THREADS 512
 #define MG_NW (MG_THREADS / 64)
 #define MG_NP3 4                  // LayerNorm elements per lane of one of the six gather waves: d <= 1536
-#define MG_SPIN_LIMIT 300000u     // polls (~0.5 us each) before a hand-off is declared dead
+#define MG_SPIN_LIMIT 20000u      // polls (~0.5 us each, ~10 ms) before a hand-off is declared dead: the host then pauses the one-launch step and tries again later
 #ifndef MG_DEFER
 #define MG_DEFER 1                // request a wave's next weights after the CU's next gather instead of right away (BIG assist re-fetches stay in place)
 #endif
@@ -772,6 +772,8 @@ __device__ __forceinline__ void mg_final(mg_kargs A, mg_ctl & c, unsigned char *
     }
     mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, (A->n_layer * 8) * 8 + 3, mg_now());
     if (A->dbg) { mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, 3022, (unsigned) clock64()); mg_trace(A, blockIdx.x == 0 && wave == 0 && lane == 0, 3023, mg_now()); }
+    // this launch ran: the host accepts a step only with its own number behind the logits (a launch that never started leaves the status word 0 too)
+    if (blockIdx.x == 0 && wave == 0 && lane == 0) ((GAS unsigned *) A->logits)[A->n_vocab + 2] = c.seq;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -802,6 +804,9 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     // 6, 7, which hold no logits rows until the last layer), and waves 3, 4 ask for the first half of their FC2 rows right after FC1 - an assist
     // that fetches on demand exposes an HBM round trip per group (P7 5.3 -> ~1.5 us, P8 5.9 -> ~4 us per layer on large-v3).
     constexpr bool BIGP = BIG && MG_DEFER;
+    // (fc1x / fc1cnt sit in the xin area at byte 7 MAX_D = 8960 .. 9092.  The whole-block form runs for d <= 768 only (QB = Q && !BIG): the widest thing
+    //  ever written into xin there is the FC2 operand - quants [4d <= 3072] bytes at 0, block scales [4d / 32 <= 96] floats at 6 MAX_D = 7680 .. 8064 -, so
+    //  no gather reaches byte 8960; the counter is never reset, only compared modulo 4.)
     float    * fc1x   = (float *) (smem + WA_MEGA_MAX_D * 4 + 7 * WA_MEGA_MAX_D);           // [32] the block's GELU outputs (behind xq / xd in the xin area)
     unsigned * fc1cnt = (unsigned *) (smem + WA_MEGA_MAX_D * 4 + 7 * WA_MEGA_MAX_D + 128);  // arrivals, never reset: a multiple of 4 after every layer
 
@@ -999,12 +1004,14 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
                 float gl = v;                                      // wa_gelu (vec.h:571-585) through the F16 table (LDS copy)
                 if (v <= -10.0f) gl = 0.0f; else if (v < 10.0f) gl = h2f(gelu_l[t.valid ? f2h(v) : 0]);
                 if ((lane & 7) == 0) fc1x[8 * (wave - 1) + (lane >> 3)] = gl;
+                MG_CHAOS_AT(51u);
                 unsigned arrived = 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (LDS operations of a wave execute in order: the values are in place before the count moves)
                 if (lane == 0) arrived = __hip_atomic_fetch_add(fc1cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 arrived = (unsigned) __builtin_amdgcn_readfirstlane((int) arrived);
                 asm volatile("" ::: "memory");
                 if ((arrived & 3u) == 3u && 32 * wg < d4) {               // all 32 values are there: quantize_row_q8_0 of the block (as mq_put), by lanes 0..31
+                    MG_CHAOS_AT(52u);
                     const float y = fc1x[lane & 31];
                     float a = fabsf(y);
                     a = fmaxf(a, dpp_f32<0x128>(a)); a = fmaxf(a, dpp_f32<0x124>(a)); a = fmaxf(a, dpp_f32<0x122>(a)); a = fmaxf(a, dpp_f32<0x121>(a));
@@ -1583,14 +1590,17 @@ size_t wa_mega_lds_bytes() {
     return MG_PICK_OFF + MG_PICK_BYTES;
 }
 
-void wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg) {
-    static bool attr_set = false;
+bool wa_launch_decode_mega(hipStream_t s, const wa_mega_args & a, int n_wg) {
+    static bool attr_set[64] = {};          // per device (the attribute belongs to the device's copy of the code object)
     const size_t lds = wa_mega_lds_bytes();
-    if (!attr_set) {
-        (void) hipFuncSetAttribute((const void *) k_decode_mega, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        (void) hipFuncSetAttribute((const void *) k_decode_mega_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        attr_set = true;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    if (!attr_set[dev & 63]) {
+        if (hipFuncSetAttribute((const void *) k_decode_mega, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *) k_decode_mega_q, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) return false;
+        attr_set[dev & 63] = true;
     }
     if (a.quant) hipLaunchKernelGGL(k_decode_mega_q, dim3(n_wg), dim3(MG_THREADS), lds, s, a);
     else         hipLaunchKernelGGL(k_decode_mega, dim3(n_wg), dim3(MG_THREADS), lds, s, a);
+    return hipGetLastError() == hipSuccess;
 }

@@ -33,7 +33,7 @@ __device__ __forceinline__ mb_kargs mb_uniform(mb_kargs p) {
 #define MB_THREADS 512
 #define MB_NW 8
 #define MB_NCW 7                  // waves that compute products; wave 7 streams the weights
-#define MB_SPIN_LIMIT 40000u      // polls (~0.5 us each) before a hand-off is declared dead
+#define MB_SPIN_LIMIT 20000u      // polls (~0.5 us each, ~10 ms) before a hand-off is declared dead (the host pauses the form and tries again later)
 #define MB_TRACE_LAYER 5
 #define MB_PAD 64                 // bytes behind every weight row in LDS: consecutive rows start 16 banks apart
 
@@ -59,6 +59,21 @@ __device__ __forceinline__ void mb_barrier_w(int wave) {
 __device__ __forceinline__ void mb_trace(mb_kargs A, bool who, int slot) {
     if (A->dbg && who) ((GAS unsigned *) A->dbg)[slot] = (unsigned) wall_clock64();
 }
+
+// MB_CHAOS (the test build, libwhisper_chaos.so): waves and whole workgroups stall at random for ~25 us in front of products, units and gathers,
+// so that the rest of the workgroup - and of the grid - runs far ahead of them.  Results must not change.
+#ifdef MB_CHAOS
+__device__ __forceinline__ void mb_chaos(unsigned a, unsigned b, unsigned c_, unsigned phase, unsigned seq) {
+    unsigned h = (a * 2654435761u) ^ (b * 40503u) ^ (c_ * 2246822519u) ^ (phase * 3266489917u) ^ (seq * 668265263u);
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    if ((h & 7u) == 0u) for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#define MB_CHAOS_AT(phase) mb_chaos((unsigned) blockIdx.x, (unsigned) (threadIdx.x >> 6), (unsigned) l, (phase), seq)
+#define MB_CHAOS_WG(phase) mb_chaos((unsigned) blockIdx.x, 99u, (unsigned) l, (phase), seq)
+#else
+#define MB_CHAOS_AT(phase) do { } while (0)
+#define MB_CHAOS_WG(phase) do { } while (0)
+#endif
 
 __device__ __forceinline__ gu64 * mb_edge(mb_kargs A, int layer, int e) {
     return (gu64 *) A->granules + ((size_t) layer * WA_MEGA_EDGES + e) * ((size_t) A->B * A->row_gr);
@@ -1050,6 +1065,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
                 if (ck == 0 && (p == 0 || p == 2 || p == 4)) request_ln(l, p);      // (the LayerNorm before this phase has been through: its parameters may go)
             } else {
                 const int Rc = min(ph.rc, ph.r - ck * ph.rc);
+                MB_CHAOS_AT(10u + p);
                 tasks(ph, slot0 + (size_t) par * slot_bytes, wg * ph.r + ck * ph.rc, Rc, ck * ph.rc);
             }
             par ^= 1;
@@ -1093,6 +1109,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
         MB_T(0);
+        MB_CHAOS_AT(27u);
         // ---------------- P1: LayerNorm + q|k|v ----------------
         if (wave < B) mb_ln_row<NP, Q>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, l == 0 ? Y.ln1_w : nullptr, l == 0 ? Y.ln1_b : nullptr,
                                        wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), xres + wave * 8, row_d, r_d, 100u + l);
@@ -1119,9 +1136,11 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         });
         MB_T(2);
         // ---------------- P2: self-attention ----------------
+        MB_CHAOS_WG(20u); MB_CHAOS_AT(21u);
         for (int u = wg; u < B * H; u += nwg) mb_unit_self<Q>(A, c, area, l, u / H, u % H, tid);
         MB_T(3);
         // ---------------- P3: out-projection + residual ----------------
+        MB_CHAOS_AT(22u);
         gather_rows(mb_edge(A, l, E_AO), d, 200u + l);
         auto resid_epi = [&](gu64 * ex) {
             return [&, ex](auto & res, int b0, int b1, int n, bool has, float bias, float) {
@@ -1157,6 +1176,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         });
         MB_T(7);
         // ---------------- P5: cross-attention ----------------
+        MB_CHAOS_WG(23u); MB_CHAOS_AT(24u);
         for (int u = wg; u < B * H * 4; u += nwg) {
             const int bh = u >> 2;
             mb_cross_regs CR;       // (asked for here: earlier - across the cross-query products - the 72 registers cost those products 2 us and won 0.8)
@@ -1165,6 +1185,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         }
         MB_T(8);
         // ---------------- P6: out-projection + residual ----------------
+        MB_CHAOS_AT(25u);
         gather_rows(mb_edge(A, l, E_AO2), d, 400u + l);
         MB_T(9);
         run_phase(l, 3, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) { prod8(ph, slot, row_base, Rc, nullptr, xin, opD, resid_epi(mb_edge(A, l, E_X2))); });
@@ -1207,6 +1228,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         }
         MB_T(12);
         // ---------------- P8: FC2 + residual ----------------
+        MB_CHAOS_AT(26u);
         gather_rows(mb_edge(A, l, E_HF), d4, 600u + l);
         MB_T(13);
         run_phase(l, 5, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
