@@ -293,6 +293,68 @@ def test_medium_wide_beam5_zh_dtw_live(wrs, amd_lib, ref_lib):
     a.free(); r.free()
 
 
+def _full_depth(wrs, amd_lib, ref_lib, mp, d, n_mels_note):
+    """encoder output + three teacher-forced decoder passes (a prompt, a single token through the one-launch step, a 5-token batch through the
+    several-rows step) of a FULL-DEPTH model against the reference engine on the same inputs; the one-launch forms must be the ones that ran."""
+    a, r = _both(wrs, amd_lib, ref_lib, mp)
+    ref_lib.ref_shim_get_embd_enc.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    amd_lib.whisper_amd_mega_enabled.argtypes = [C.c_void_p]
+    pcm = wsynth.synth_audio(480000, 0)
+    sa, sr = a.create_state(), r.create_state()
+    sa.pcm_to_mel(pcm); sa.encode(0)
+    sr.pcm_to_mel(pcm, 8); sr.encode(0, 16)
+    x = np.empty(1500 * d, np.float32)
+    ref_lib.ref_shim_get_embd_enc(sr.ptr, x.ctypes.data_as(C.POINTER(C.c_float)), x.size)
+    assert digest(_get(amd_lib, "whisper_amd_get_embd_enc", sa, 1500 * d)) == digest(x), n_mels_note
+    sot = a.token_sot()
+    for toks, n_past in (([sot, sot + 1, a.token_transcribe()], 0), ([a.token_beg() + 3], 3), ([4321, 777, 31000, 15, 50], 4)):
+        sa.decode(toks, n_past); sr.decode(toks, n_past, 16)
+        assert digest(sa.get_logits_last(len(toks))) == digest(sr.get_logits_last(len(toks))), (toks, n_past)
+    assert amd_lib.whisper_amd_mega_enabled(sa.ptr) == 1
+    served, back = sa.rows_stats()
+    assert served == 2 and back == 0, (served, back)          # the prompt and the 5-token batch
+    for x_ in (sa, sr):
+        x_.free()
+    a.free(); r.free()
+
+
+def test_medium_full_depth_live(wrs, amd_lib, ref_lib):
+    """BASELINE config 4's model at FULL depth: ggml-medium shape (d 1024, 16 heads, 24 + 24 layers)."""
+    _full_depth(wrs, amd_lib, ref_lib, wsynth.model_path("medium"), 1024, "medium")
+
+
+def test_large_v3_q5_0_full_depth_live(wrs, amd_lib, ref_lib):
+    """BASELINE config 5's model at FULL depth: ggml-large-v3 shape (d 1280, 20 heads, 32 + 32 layers, 128 mels, 51866 tokens), Q5_0 weights written
+    by the reference's own quantizer."""
+    _full_depth(wrs, amd_lib, ref_lib, wsynth.quant_model_path("large-v3", "q5_0"), 1280, "large-v3 q5_0")
+
+
+def test_small_shape_full_greedy_live(wrs, amd_lib, ref_lib):
+    """BASELINE.json's headline workload as a test: ggml-small shape, greedy full() of a 30 s chunk - segments, ids, p, plog identical to the
+    reference engine's (bench.py checks the same inside its cpu_baseline leg)."""
+    mp = wsynth.model_path("small")
+    a, r = _both(wrs, amd_lib, ref_lib, mp)
+    pcm = wsynth.synth_audio(480000, 0)
+    fkw = dict(strategy=0, best_of=1, temperature_inc=0.0, language="en", no_context=True)
+    sa, sr = a.create_state(), r.create_state()
+    sa.full(_params(wrs, amd_lib, fkw), pcm)
+    sr.full(_params(wrs, ref_lib, fkw, n_threads=16), pcm)
+    # the decode loop's own record of decoder 0 (the random model writes 220 tokens without a closing timestamp, i.e. possibly no segment):
+    # raw token ids and the loop's decisions, then the segment lists
+    info_r, info_g = (C.c_double * 8)(), (C.c_double * 8)()
+    ids_r, ids_g = (C.c_int32 * 512)(), (C.c_int32 * 512)()
+    ref_lib.ref_shim_decoder_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]
+    amd_lib.whisper_amd_decoder_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]
+    n_r = ref_lib.ref_shim_decoder_info(sr.ptr, 0, info_r, ids_r, 512)
+    n_g = amd_lib.whisper_amd_decoder_info(sa.ptr, 0, info_g, ids_g, 512)
+    assert n_r > 100 and n_r == n_g and list(ids_r[:n_r]) == list(ids_g[:n_g])
+    assert list(info_r) == list(info_g)             # failed / completed / has_ts / seek_delta / result_len / avg_logprobs / entropy / no_speech_prob
+    assert _segs(sa) == _segs(sr)
+    for x_ in (sa, sr):
+        x_.free()
+    a.free(); r.free()
+
+
 # ------------------------------------------------------------------------------------------------------------
 # compiled callers at the boundary (tests/native/, built by oracle/Makefile in the container)
 # ------------------------------------------------------------------------------------------------------------
