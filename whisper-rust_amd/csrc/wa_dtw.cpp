@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 void wa_dtw_timestamps(whisper_context * ctx, whisper_state * st, const whisper_full_params & params, int i_segment, size_t n_segments,
                        int seek, int n_frames, int medfilt_width) {
@@ -78,8 +79,14 @@ void wa_dtw_timestamps(whisper_context * ctx, whisper_state * st, const whisper_
     }
     (void) hipFree(st->d_aheads_qk); st->d_aheads_qk = nullptr;
 
-    // ggml_norm over the token axis, eps 1e-9 (whisper.cpp:8864, ops.cpp:3225-3242)
-    for (int kk = 0; kk < n_heads; ++kk)
+    // Per alignment head (independent: spread over a few host threads - a medium model's 32 heads x 223 tokens x 750 frames took ~0.5 s
+    // in one thread with a sort per median):
+    //   ggml_norm over the token axis, eps 1e-9 (whisper.cpp:8864, ops.cpp:3225-3242), in place in w[.][j][t];
+    //   7-wide median over the audio axis with reflect padding, per token (whisper.cpp:8737-8770) -> med[kk][t][j].  The median of 7 is a
+    //   13-exchange selection network on a transposed copy of the head (rows of frames: it vectorises); other widths sort.
+    if (medfilt_width >= n_audio_tokens) { WA_WARN("%s: too few audio frames for the median filter\n", __func__); return; }
+    std::vector<float> med((size_t) n_heads * n_tokens * n_audio_tokens);  // med[kk][t][j]
+    auto one_head = [&](int kk) {
         for (int j = 0; j < n_audio_tokens; ++j) {
             float * x = &w[(size_t) n_tokens * (j + (size_t) n_audio_tokens * kk)];
             double sum = 0.0;
@@ -91,36 +98,48 @@ void wa_dtw_timestamps(whisper_context * ctx, whisper_state * st, const whisper_
             const float scale = 1.0f / sqrtf(variance + 1e-9f);
             for (int t = 0; t < n_tokens; ++t) x[t] = x[t] * scale;
         }
-
-    // 7-wide median over the audio axis with reflect padding, per (head, token) (whisper.cpp:8737-8770),
-    // then mean over heads (F64 sum in head order, ops.cpp:2033-2041 / vec.h:908-914), times -1
-    std::vector<float> cost_in((size_t) n_tokens * n_audio_tokens);          // x[t][j]
-    {
-        std::vector<float> med((size_t) n_heads * n_tokens * n_audio_tokens);  // med[kk][t][j]
-        std::vector<float> filt;
-        filt.reserve(medfilt_width);
-        if (medfilt_width >= n_audio_tokens) { WA_WARN("%s: too few audio frames for the median filter\n", __func__); return; }
-        for (int kk = 0; kk < n_heads; ++kk)
-            for (int t = 0; t < n_tokens; ++t)
-                for (int j = 0; j < n_audio_tokens; ++j) {
-                    for (int off = -medfilt_width / 2; off <= medfilt_width / 2; ++off) {
-                        int idx = j + off;
-                        if (idx < 0) idx = -idx; else if (idx >= n_audio_tokens) idx = 2 * (n_audio_tokens - 1) - idx;
-                        filt.push_back(w[t + (size_t) n_tokens * (idx + (size_t) n_audio_tokens * kk)]);
-                    }
-                    std::sort(filt.begin(), filt.end());
-                    med[((size_t) kk * n_tokens + t) * n_audio_tokens + j] = filt[filt.size() / 2];
-                    filt.clear();
+        const int hw = medfilt_width / 2, M_ = n_audio_tokens;
+        std::vector<float> row((size_t) M_ + 2 * hw), filt((size_t) medfilt_width);
+        for (int t = 0; t < n_tokens; ++t) {
+            for (int j = 0; j < M_; ++j) row[hw + j] = w[t + (size_t) n_tokens * (j + (size_t) M_ * kk)];
+            for (int o = 1; o <= hw; ++o) { row[hw - o] = row[hw + o]; row[hw + M_ - 1 + o] = row[hw + M_ - 1 - o]; }      // reflect (idx -> -idx, 2 (M - 1) - idx)
+            float * out = &med[((size_t) kk * n_tokens + t) * M_];
+            if (medfilt_width == 7) {
+                const float * r = row.data();
+                for (int j = 0; j < M_; ++j) {
+                    float p0 = r[j], p1 = r[j + 1], p2 = r[j + 2], p3 = r[j + 3], p4 = r[j + 4], p5 = r[j + 5], p6 = r[j + 6];
+#define WA_CX(a, b) do { const float lo_ = std::min(a, b), hi_ = std::max(a, b); a = lo_; b = hi_; } while (0)
+                    WA_CX(p0, p5); WA_CX(p0, p3); WA_CX(p1, p6); WA_CX(p2, p4); WA_CX(p0, p1); WA_CX(p3, p5); WA_CX(p2, p6);
+                    WA_CX(p2, p3); WA_CX(p3, p6); WA_CX(p4, p5); WA_CX(p1, p4); WA_CX(p1, p3); WA_CX(p3, p4);
+#undef WA_CX
+                    out[j] = p3;
                 }
-        for (int t = 0; t < n_tokens; ++t)
-            for (int j = 0; j < n_audio_tokens; ++j) {
-                double sum = 0.0;
-                for (int kk = 0; kk < n_heads; ++kk) sum += (double) med[((size_t) kk * n_tokens + t) * n_audio_tokens + j];
-                float v = (float) sum;
-                v /= (float) n_heads;
-                cost_in[(size_t) t * n_audio_tokens + j] = v * -1.0f;
+            } else {
+                for (int j = 0; j < M_; ++j) {
+                    std::copy(row.begin() + j, row.begin() + j + medfilt_width, filt.begin());
+                    std::sort(filt.begin(), filt.end());
+                    out[j] = filt[filt.size() / 2];
+                }
             }
+        }
+    };
+    {
+        const int n_thr = std::max(1, std::min(n_heads, 8));
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_thr; ++i) th.emplace_back([&, i] { for (int kk = i; kk < n_heads; kk += n_thr) one_head(kk); });
+        for (int kk = 0; kk < n_heads; kk += n_thr) one_head(kk);
+        for (auto & t_ : th) t_.join();
     }
+    // mean over heads (F64 sum in head order, ops.cpp:2033-2041 / vec.h:908-914), times -1
+    std::vector<float> cost_in((size_t) n_tokens * n_audio_tokens);          // x[t][j]
+    for (int t = 0; t < n_tokens; ++t)
+        for (int j = 0; j < n_audio_tokens; ++j) {
+            double sum = 0.0;
+            for (int kk = 0; kk < n_heads; ++kk) sum += (double) med[((size_t) kk * n_tokens + t) * n_audio_tokens + j];
+            float v = (float) sum;
+            v /= (float) n_heads;
+            cost_in[(size_t) t * n_audio_tokens + j] = v * -1.0f;
+        }
 
     // drop the sot sequence and eot (whisper.cpp:8880-8882): rows [sot_len, n_tokens - 1)
     const int N = n_tokens - (int) sot_len - 1, M = n_audio_tokens;

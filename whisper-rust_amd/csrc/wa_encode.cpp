@@ -80,7 +80,7 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
     if (!dev_alloc(st.d_xn,   (size_t) tpad * d)) return false;
     if (!dev_alloc(st.d_qk,   (size_t) tpad * 2 * d)) return false;
     if (!dev_alloc(st.d_vt,   (size_t) d * tpad)) return false;
-    if (ctx.exact && ctx.model.wtype == 1 && hp.n_audio_state == hp.n_audio_head * 64)      // probability buffers of the MFMA reference-order attention
+    if ((ctx.exact || ctx.model.wtype != 1) && hp.n_audio_state == hp.n_audio_head * 64)      // probability buffers of the MFMA reference-order attention
         if (!dev_alloc(st.d_attn_p, (size_t) hp.n_audio_head * tpad * tpad) || !dev_alloc(st.d_attn_pl, (size_t) hp.n_audio_head * tpad * 32)) return false;
     if (!dev_alloc(st.d_ao,   (size_t) tpad * d)) return false;
     if (!dev_alloc(st.d_ff,   (size_t) tpad * 4 * d)) return false;
@@ -304,9 +304,18 @@ bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_a
             const auto & L = m.enc[il];
             // (LayerNorm and attention quantise their F32 result rows themselves: wa_q8_store)
             wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.attn_ln.w, L.attn_ln.b, hp.eps, nullptr, 0, nullptr, 0, st.d_q8, st.d_q8d);
+            static const bool no_mfma_attn = getenv("WHISPER_AMD_NO_EXACT_MFMA") != nullptr;
+            if (st.d_attn_p && T >= 128 && !no_mfma_attn) {
+                // q, k, v are F16 here whatever the weight type (whisper.cpp:2181-2202): the reference-order attention on the matrix cores as for an
+                // F16 model (Q | K row-major, V transposed); its F32 result is quantised for the out-projection by one more launch
+                { wa_epi e; e.bias = L.qkv.b; e.out = st.d_qk; e.ldo = 2 * d; e.out2 = st.d_vt; e.ldo2 = tpad; e.split0 = 2 * d; qmul(WA_EPI_ENC_QKV, L.qkv, T, e); }
+                wa_launch_attn_exact_mfma(s, st.d_qk, 2 * d, st.d_vt, tpad, T, d, H, KQscale, st.d_attn_p, st.d_attn_pl, (T + 127) & ~127, st.d_ao, d, st.d_q32a);
+                wa_launch_quantize_q8_0(s, st.d_q32a, d, T, d, st.d_q8, st.d_q8d);
+            } else {
             { wa_epi e; e.bias = L.qkv.b; e.out = st.d_ff; e.ldo = 3 * d; qmul(WA_EPI_F16, L.qkv, T, e); }
             wa_launch_attn_exact(s, st.d_ff, 3 * d, st.d_ff + d, 64, 3 * d, st.d_ff + 2 * d, 64, 3 * d, H, T, T, nullptr, KQscale,
                                  st.d_att_partial, st.d_att_pleft, st.d_ao, d, nullptr, nullptr, nullptr, st.d_q8, st.d_q8d);
+            }
             { wa_epi e; e.bias = L.out.b; e.out = st.d_x; e.ldo = d; e.resid = st.d_x; e.ldr = d; qmul(WA_EPI_RESID, L.out, T, e); }
             wa_launch_layernorm_exact(s, st.d_x, d, T, d, L.mlp_ln.w, L.mlp_ln.b, hp.eps, nullptr, 0, nullptr, 0, st.d_q8, st.d_q8d);
             { wa_epi e; e.bias = L.fc1.b; e.gelu = m.d_gelu; e.out = st.d_q32b; e.ldo = 4 * d; qmul(WA_EPI_GELU_F32, L.fc1, T, e); }

@@ -312,7 +312,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_exact_mfma(const wa_f16 * __res
             for (int c = 0; c < 32; ++c) prod[c] = (float) vl[c >> 3][c & 7] * (float) pv[c >> 3][c & 7];
 #pragma unroll
             for (int c = 0; c < 32; ++c) if (c < nl) sumf += (double) prod[c];
-            if (om + j < M) ((wa_f16 *) e.out)[(size_t) (om + j) * e.ldo + blockIdx.y * 64 + on] = f2h((float) sumf);
+            if (om + j < M) {
+                if (e.out3) ((float *) e.out3)[(size_t) (om + j) * e.ldo3 + blockIdx.y * 64 + on] = (float) sumf;      // quantised models: F32, quantised by the next launch
+                else ((wa_f16 *) e.out)[(size_t) (om + j) * e.ldo + blockIdx.y * 64 + on] = f2h((float) sumf);
+            }
         }
         return;
     }
@@ -1053,13 +1056,14 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * 
 }
 
 void wa_launch_attn_exact_mfma(hipStream_t s, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
-                               wa_f16 * p, wa_f16 * p_left, int kvp, wa_f16 * out, int ldo) {
+                               wa_f16 * p, wa_f16 * p_left, int kvp, wa_f16 * out, int ldo, float * out32) {
     static bool attr_done = false;
     const int lds = AS_Q * (kvp + 8) * (int) sizeof(float);
     if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_attn_scores_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr_done = true; }
     hipLaunchKernelGGL(k_attn_scores_mfma, dim3(n_head, (T + AS_Q - 1) / AS_Q), dim3(AS_THREADS), lds, s, qk, ldqk, d, T, scale, p, p_left, kvp);
     const int np = T & ~31;
     wa_epi e; e.out = out; e.ldo = ldo; e.out2 = p_left; e.bs_o2 = (long long) T * 32; e.aux0 = np; e.aux1 = T - np;
+    e.out3 = out32; e.ldo3 = ldo;
     e.bs_a = (long long) T * kvp; e.bs_w = (long long) 64 * ldvt;
     gemm_exact_mfma_launch<WA_EPI_ATTN_PV>(s, p, kvp, vt, ldvt, T, 64, (np + 127) & ~127, e, n_head);
 }

@@ -92,7 +92,8 @@ void wa_launch_layernorm_exact(hipStream_t stream, const float * x, int ldx, int
 // cells' probabilities `p_left` f16 [n_head][T][32]), then P V as a batched reference-order GEMM against V^T.
 // qk [T][ldqk] (Q | K), vt [d][ldvt] (V transposed, ldvt >= kvp, finite beyond T), kvp = T rounded up to 128.
 void wa_launch_attn_exact_mfma(hipStream_t stream, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
-                               wa_f16 * p, wa_f16 * p_left, int kvp, wa_f16 * out, int ldo);
+                               wa_f16 * p, wa_f16 * p_left, int kvp, wa_f16 * out, int ldo,
+                               float * out32 = nullptr /* when set: the result in F32 [T][ldo] instead (quantised models: the next product quantises it) */);
 void wa_launch_attn_exact(hipStream_t stream, const wa_f16 * q, int ldq, const wa_f16 * kbase, size_t k_head_stride, int k_row_stride,
                           const wa_f16 * vbase, size_t v_head_stride, int v_row_stride, int n_head, int n_tokens, int n_kv, const int8_t * mask,
                           float scale, float * partial, wa_f16 * p_left, wa_f16 * out, int ldo, float * qk_out, const int * dyn_n_kv = nullptr,
