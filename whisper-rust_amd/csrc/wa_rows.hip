@@ -429,7 +429,7 @@ __device__ __forceinline__ unsigned mb_pack_h2(unsigned h) { return (h & 0xffffu
 // -------------------------------------------------------------------------------------------------
 // attention scratch in LDS (aliases the FC2-input area, which holds nothing during an attention phase)
 // -------------------------------------------------------------------------------------------------
-#define MB_ATT_BYTES (32 * 64 * 4 + WA_ROWS_MAXKV * 4 + WA_ROWS_MAXKV * 2 + (WA_ROWS_MAXKV / 8) * 4 + 32 * 64 * 2 + 2048 + 512)
+#define MB_ATT_BYTES 34816          /* self-attention unit: 28160; cross-attention unit: 17408 + 2 x 8192 of F64 for its finish */
 
 __device__ __forceinline__ float mb_score(const u32x4 & ka, const u32x4 & kb, const float (&qa)[8], const float (&qb)[8], float scale) {
     const wa_f16 * k8a = (const wa_f16 *) &ka, * k8b = (const wa_f16 *) &kb;
@@ -654,46 +654,58 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
 }
 
 // -------------------------------------------------------------------------------------------------
-// unit: a quarter of the cross-attention of (token row b, head h) over the row's encoder K / V (whisper.cpp:2683-2758); arithmetic and
-// split of wa_mega.hip: mg_role_cross - quarter w owns the cells c with (c mod 32) in [8w, 8w + 8) = whole soft-max groups and whole
-// P V chains; the four quarters exchange maxima, F64 partial sums and chain sums through the (layer, row, head) granule area.
+// unit: one of P parts (4 quarters, or 2 halves when the quarters of all rows would not fit the grid in one round) of the cross-attention of
+// (token row b, head h) over the row's encoder K / V (whisper.cpp:2683-2758); arithmetic and split of wa_mega.hip: mg_role_cross - part w owns
+// the cells c with (c mod 32) in [NCH w, NCH w + NCH), NCH = 32 / P: whole soft-max groups of 8 cells and whole P V chains; the parts
+// exchange maxima, F64 partial sums and chain sums through the (layer, row, head) granule area.  Local index o = NCH s + r  <->  cell 32 s + NCH w + r.
 // -------------------------------------------------------------------------------------------------
 #define MB_CSTEPS 48
 #define MB_CGR_MAX 0
 #define MB_CGR_SUM 8
-#define MB_CGR_PART 64
+#define MB_CGR_PART 64               // chain sums of the parts 1 .. P - 1: [P - 1][NCH][64]; behind them their leftover probabilities [P - 1][NCH]
 
-struct mb_cross_regs { u32x4 ka[3], kb[3]; unsigned short vv[MB_CSTEPS]; };
-// own keys (24 registers) and own chain elements of quarter w of (row b, head h): unconditional, clamped loads - all in flight together
-__device__ __forceinline__ void mb_cross_load(mb_kargs A, int l, int b, int h, int w, int tid, mb_cross_regs & R) {
+template <int P> struct mb_cross_regs { u32x4 ka[12 / P], kb[12 / P]; unsigned short vv[4 / P][MB_CSTEPS]; };
+// own keys and own chain elements: unconditional, clamped loads - all in flight together
+template <int P>
+__device__ __forceinline__ void mb_cross_load(mb_kargs A, int l, int b, int h, int w, int tid, mb_cross_regs<P> & R) {
+    constexpr int NCH = 32 / P, CPW = 4 / P;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = A->T, tpad = A->cross_tpad, a = tid & 3, ks = tid >> 2, nsteps = (T & ~31) >> 5;
     const gch kp = (gch) A->rows[b].cross_k + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
     const gch vp = (gch) A->rows[b].cross_v + (size_t) l * A->cross_layer_stride + (size_t) h * tpad * 64;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int o = p * 128 + ks, c0 = 32 * (o >> 3) + 8 * w + (o & 7), cc = c0 < T ? c0 : T - 1;
+    for (int p = 0; p < 12 / P; ++p) {
+        const int o = p * 128 + ks, c0 = 32 * (o / NCH) + NCH * w + (o % NCH), cc = c0 < T ? c0 : T - 1;
         R.ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 8 * a); R.kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * 64 + 32 + 8 * a);
     }
 #pragma unroll
-    for (int s = 0; s < MB_CSTEPS; ++s) { const int sc_ = s < nsteps ? s : (nsteps > 0 ? nsteps - 1 : 0); R.vv[s] = *(const GAS unsigned short *) (vp + (size_t) (32 * sc_ + 8 * w + wave) * 64 + lane); }
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int s = 0; s < MB_CSTEPS; ++s) {
+            const int sc_ = s < nsteps ? s : (nsteps > 0 ? nsteps - 1 : 0);
+            R.vv[c][s] = *(const GAS unsigned short *) (vp + (size_t) (32 * sc_ + NCH * w + CPW * wave + c) * 64 + lane);
+        }
 }
 
-template <bool Q = false>
-__device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int w, int tid, bool tw, const mb_cross_regs & R) {
+template <bool Q, int P>
+__device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int w, int tid, bool tw, const mb_cross_regs<P> & R) {
+    constexpr int NCH = 32 / P, CPW = 4 / P, NK = NCH * MB_CSTEPS;          // chains of this part, chains per wave, local cell slots
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned seq = c.seq;
 #define MB_TC(k) mb_trace(A, tw, l * 32 + 16 + (k))
     MB_TC(0);
-    float  * part  = (float *) area;                                  // [32][64]
-    wa_f16 * vleft = (wa_f16 *) (area + 8192);                        // [32][64]
-    float  * sc    = (float *) (area + 8192 + 4096);                  // [384]
-    wa_f16 * p16   = (wa_f16 *) (area + 8192 + 4096 + 1536);          // [8][48]
-    wa_f16 * pleft = (wa_f16 *) (area + 8192 + 4096 + 1536 + 768);    // [32]
-    wa_f16 * qs    = (wa_f16 *) (area + 8192 + 4096 + 1536 + 768 + 64);
-    double * redd  = (double *) (area + 8192 + 4096 + 1536 + 768 + 64 + 128);
-    float  * red   = (float *) (area + 8192 + 4096 + 1536 + 768 + 64 + 128 + 64);
+    // LDS: part [32][64] f32 | vleft [32][64] f16 | sc [768] f32 | p16 [16][48] f16 | pleft [32] f16 | qs [64] f16 | redd [8] f64 | red [8] + bc [4] f32 |
+    //      two F64 areas [16][64] for the finish
+    float  * part  = (float *) area;
+    wa_f16 * vleft = (wa_f16 *) (area + 8192);
+    float  * sc    = (float *) (area + 12288);
+    wa_f16 * p16   = (wa_f16 *) (area + 15360);
+    wa_f16 * pleft = (wa_f16 *) (area + 16896);
+    wa_f16 * qs    = (wa_f16 *) (area + 16960);
+    double * redd  = (double *) (area + 17088);
+    float  * red   = (float *) (area + 17152);
     float  * bc    = red + 8;
+    double * dbl0  = (double *) (area + 17408), * dbl1 = (double *) (area + 17408 + 8192);
     const int T = A->T, tpad = A->cross_tpad, H = A->n_head;
     const float kq_scale = A->kq_scale;
     const int a = tid & 3, ks = tid >> 2;
@@ -712,15 +724,15 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
     }
     mb_barrier();
     MB_TC(2);
-    // ---- scores of the own cells (local index o = 8 s + r  <->  cell 32 s + 8 w + r) ----
+    // ---- scores of the own cells ----
     float lmax = -INFINITY;
     {
         float qa[8], qb[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { qa[i] = h2f(qs[8 * a + i]); qb[i] = h2f(qs[32 + 8 * a + i]); }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const int o = p * 128 + ks, cc = 32 * (o >> 3) + 8 * w + (o & 7);
+        for (int p = 0; p < 12 / P; ++p) {
+            const int o = p * 128 + ks, cc = 32 * (o / NCH) + NCH * w + (o % NCH);
             const float r = mb_score(R.ka[p], R.kb[p], qa, qb, kq_scale);
             if (cc < T) { if (a == 0) sc[o] = r; lmax = fmaxf(lmax, r); }
         }
@@ -729,32 +741,34 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
     if (lane == 0) red[wave] = lmax;
     MB_TC(3);
     mb_barrier();
-    if (wave == 0) {        // (1) maxima of the four quarters
+    if (wave == 0) {        // (1) maxima of the parts
         float m = red[0];
 #pragma unroll
         for (int k = 1; k < MB_NW; ++k) m = fmaxf(m, red[k]);
         if (lane == 0) gr_store(X + MB_CGR_MAX + w, seq, __float_as_uint(m));
         unsigned v[1];
-        mb_sweep<1>(X + MB_CGR_MAX, [&](int) { return lane < 4 ? lane : -1; }, c, lane, v, 2100u + l);
-        float g = lane < 4 ? __uint_as_float(v[0]) : -INFINITY;
+        mb_sweep<1>(X + MB_CGR_MAX, [&](int) { return lane < P ? lane : -1; }, c, lane, v, 2100u + l);
+        float g = lane < P ? __uint_as_float(v[0]) : -INFINITY;
         g = fmaxf(g, dpp_f32<0x4e>(g)); g = fmaxf(g, dpp_f32<0xb1>(g));      // max over lanes 0..3
         if (lane == 0) bc[0] = g;
     }
     mb_barrier();
     MB_TC(4);
     const float mx = bc[0];
-    // ---- exp, group sums (8-lane tree = ops.cpp's), F64 partial sum: thread = one own cell ----
+    // ---- exp, group sums (8-lane tree = ops.cpp's), F64 partial sum: a thread per own cell (ops.cpp:4792-4818, vec.cpp:257-308) ----
     {
         double ps = 0.0;
-        if (tid < 8 * MB_CSTEPS) {
-            const int g = 4 * (tid >> 3) + w, cc = 8 * g + (tid & 7);
-            const float e = cc < n8 ? wa_expf(sc[tid] - mx) : (cc < T ? wa_expf_libm(sc[tid] - mx) : 0.0f);
-            sc[tid] = e;
-            float t = e + dpp_f32<0x104>(e);
+#pragma unroll
+        for (int k = 0; k < (NK + MB_THREADS - 1) / MB_THREADS; ++k) {
+            const int o = tid + MB_THREADS * k;
+            const bool in = o < NK;
+            const int oc = in ? o : 0, s_ = oc / NCH, r_ = oc % NCH, g = 4 * s_ + ((NCH * w + r_) >> 3), cc = 32 * s_ + NCH * w + r_;
+            const float e = !in ? 0.0f : cc < n8 ? wa_expf(sc[oc] - mx) : (cc < T ? wa_expf_libm(sc[oc] - mx) : 0.0f);
+            if (in) sc[oc] = e;
+            float t = e + dpp_f32<0x104>(e);        // lanes r = 0..3 of the group: e[r] + e[r+4]
             t = t + dpp_f32<0x102>(t);
-            t = t + dpp_f32<0x101>(t);
-            if (g < ng) ps = (tid & 7) == 0 ? (double) t : 0.0;
-            else ps = (double) e;
+            t = t + dpp_f32<0x101>(t);              // r = 0: the group sum, ops.cpp's tree
+            if (in) ps += g < ng ? ((tid & 7) == 0 ? (double) t : 0.0) : (double) e;       // (the n % 8 tail cells: any order, the total is certified below)
         }
         ps = wave_sum_d(ps);
         if (lane == 0) redd[wave] = ps;
@@ -766,10 +780,10 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         const u64 pb = (u64) __double_as_longlong(ps);
         if (lane == 0) { gr_store(X + MB_CGR_SUM + 2 * w, seq, (unsigned) pb); gr_store(X + MB_CGR_SUM + 2 * w + 1, seq, (unsigned) (pb >> 32)); }
         unsigned v[1];
-        mb_sweep<1>(X + MB_CGR_SUM, [&](int) { return lane < 8 ? lane : -1; }, c, lane, v, 2200u + l);
+        mb_sweep<1>(X + MB_CGR_SUM, [&](int) { return lane < 2 * P ? lane : -1; }, c, lane, v, 2200u + l);
         double tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < P; ++k) {
             const unsigned lo = __builtin_amdgcn_readlane(v[0], 2 * k), hi = __builtin_amdgcn_readlane(v[0], 2 * k + 1);
             tot += __longlong_as_double((long long) (((u64) hi << 32) | lo));
         }
@@ -781,41 +795,91 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
     mb_barrier();
     MB_TC(6);
     const float inv = bc[1];
-    if (tid < 8 * MB_CSTEPS) {
-        const int cc = 32 * (tid >> 3) + 8 * w + (tid & 7);
-        if (cc < T) {
-            const wa_f16 ph = f2h(sc[tid] * inv);
-            p16[(tid & 7) * MB_CSTEPS + (tid >> 3)] = ph;
-            if (cc >= np) { if (w == 0) pleft[cc - np] = ph; else gr_store(X + MB_CGR_PART + (w - 1) * 576 + 512 + (tid & 7), seq, (unsigned) ph); }
+    gu64 * XP = X + MB_CGR_PART;
+#pragma unroll
+    for (int k = 0; k < (NK + MB_THREADS - 1) / MB_THREADS; ++k) {
+        const int o = tid + MB_THREADS * k;
+        if (o < NK) {
+            const int s_ = o / NCH, r_ = o % NCH, cc = 32 * s_ + NCH * w + r_;
+            if (cc < T) {
+                const wa_f16 ph = f2h(sc[o] * inv);
+                p16[r_ * MB_CSTEPS + s_] = ph;         // by chain: a P V wave reads a chain's 48 probabilities as 6 x 16 bytes
+                if (cc >= np) { if (w == 0) pleft[cc - np] = ph; else gr_store(XP + (P - 1) * NCH * 64 + (w - 1) * NCH + r_, seq, (unsigned) ph); }
+            }
         }
     }
     mb_barrier();
     MB_TC(7);
-    // ---- P V: wave = own chain (cells 32 s + 8 w + wave), lane = d_head index ----
-    {
+    // ---- P V: wave = own chains (cells 32 s + NCH w + CPW wave + c), lane = d_head index ----
+#pragma unroll
+    for (int cw = 0; cw < CPW; ++cw) {
         float acc = 0.0f;
         half8 pw[MB_CSTEPS / 8];
 #pragma unroll
-        for (int k = 0; k < MB_CSTEPS / 8; ++k) pw[k] = *(const half8 *) (p16 + wave * MB_CSTEPS + 8 * k);
+        for (int k = 0; k < MB_CSTEPS / 8; ++k) pw[k] = *(const half8 *) (p16 + (CPW * wave + cw) * MB_CSTEPS + 8 * k);
 #pragma unroll
-        for (int s = 0; s < MB_CSTEPS; ++s) if (s < nsteps) acc = fmaf(h2f(R.vv[s]), (float) pw[s >> 3][s & 7], acc);
-        if (w == 0) part[wave * 64 + lane] = acc;
-        else gr_store(X + MB_CGR_PART + (w - 1) * 576 + wave * 64 + lane, seq, __float_as_uint(acc));
+        for (int s_ = 0; s_ < MB_CSTEPS; ++s_) if (s_ < nsteps) acc = fmaf(h2f(R.vv[cw][s_]), (float) pw[s_ >> 3][s_ & 7], acc);
+        if (w == 0) part[(CPW * wave + cw) * 64 + lane] = acc;
+        else gr_store(XP + ((w - 1) * NCH + CPW * wave + cw) * 64 + lane, seq, __float_as_uint(acc));
     }
     MB_TC(8);
-    if (w == 0) {           // (3) gather the other three quarters' chain sums and leftover probabilities, finish the head
-        if (wave >= 1 && wave <= 6) {
-            const int ww = (wave - 1) >> 1, half = (wave - 1) & 1;
-            gu64 * src = X + MB_CGR_PART + ww * 576;
-            unsigned v[5];
-            mb_sweep<5>(src, [&](int k) { return k < 4 ? half * 256 + 64 * k + lane : (half == 0 && lane < 8 && 8 * (ww + 1) + lane < nl ? 512 + lane : -1); }, c, lane, v, 2300u + l);
+    if (w == 0) {           // (3) gather the other parts' chain sums and leftover probabilities, finish the head
+        constexpr int NG_ = (P - 1) * NCH * 64;          // 1536 (quarters) or 1024 (halves) chain sums
+        unsigned v[NG_ / MB_THREADS + 1];
+        mb_sweep<NG_ / MB_THREADS + 1>(XP, [&](int k) {
+            if (k < NG_ / MB_THREADS) return tid + MB_THREADS * k;
+            return tid < (P - 1) * NCH && NCH + tid < nl ? NG_ + tid : -1; }, c, lane, v, 2300u + l);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) part[(8 * (ww + 1) + 4 * half + k) * 64 + lane] = __uint_as_float(v[k]);
-            if (half == 0 && lane < 8) { const int cc = 8 * (ww + 1) + lane; if (cc < nl) pleft[cc] = (wa_f16) v[4]; }
-        }
+        for (int k = 0; k < NG_ / MB_THREADS; ++k) part[NCH * 64 + tid + MB_THREADS * k] = __uint_as_float(v[k]);      // (part ww's chain r = global chain NCH ww + r)
+        if (tid < (P - 1) * NCH && NCH + tid < nl) pleft[NCH + tid] = (wa_f16) v[NG_ / MB_THREADS];
         mb_barrier();
         MB_TC(9);
-        mb_attn_finish<Q>(part, vleft, pleft, nl, mb_edge(A, l, E_AO2) + (size_t) b * A->row_gr, h, seq, tid);
+        // finish: the leftover cells (vec.cpp:221-223: F64, index order) spread over waves 1..7 - five cells each, for the 64 outputs, every product
+        // ONE v_fma_mix_f32 (F16 x F16 is exact in F32; with a -0.0 addend it is the multiplication's float), parked in LDS as F64 - while wave 0 runs
+        // the tree; what stays in series is wave 0's 32 F64 additions (wa_mega.hip: mg_attn_finish)
+        int nlo = nl;
+        asm volatile("" : "+s"(nlo));
+        if (tid >= 64) {
+            const int wv = tid >> 6, o = tid & 63;
+            float nzero = -0.0f;
+            asm volatile("" : "+v"(nzero));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int cc = 5 * (wv - 1) + i;
+                if (cc < 32) {
+                    const float pr = fmaf(h2f(vleft[cc * 64 + o]), h2f(pleft[cc]), nzero);
+                    (cc < 16 ? dbl0 : dbl1)[(cc & 15) * 64 + o] = (double) (cc < nlo ? pr : -0.0f);
+                }
+            }
+        }
+        double sumf = 0.0;
+        if (tid < 64) {
+            float s32[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) s32[r] = part[r * 64 + tid];
+            sumf = (double) wa_tree32(s32);
+        }
+        mb_barrier();
+        if (tid < 64) {
+            double dv[32];
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) dv[cc] = (cc < 16 ? dbl0 : dbl1)[(cc & 15) * 64 + tid];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) sumf += dv[cc];
+            gu64 * edge_row = mb_edge(A, l, E_AO2) + (size_t) b * A->row_gr;
+            if constexpr (Q) {
+                float dq;
+                const unsigned wq_ = mq_quant32((float) sumf, dq);
+                gu64 * eb = edge_row + (size_t) (2 * h + (tid >> 5)) * 9;
+                if ((tid & 3) == 0) gr_store(eb + ((tid & 31) >> 2), seq, wq_);
+                if ((tid & 31) == 0) gr_store(eb + 8, seq, __float_as_uint(dq));
+            } else {
+                const unsigned hv = (unsigned) f2h((float) sumf);
+                const unsigned hi = dpp_u32<0x101>(hv);
+                if ((tid & 1) == 0) gr_store(edge_row + ((h * 64 + tid) >> 1), seq, (hv & 0xffffu) | (hi << 16));
+            }
+        }
         MB_TC(10);
     }
     mb_barrier();
@@ -1177,11 +1241,14 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_T(7);
         // ---------------- P5: cross-attention ----------------
         MB_CHAOS_WG(23u); MB_CHAOS_AT(24u);
+        // a (row, head) in 4 quarters.  (Two halves - where the quarters of all rows need a second round on part of the grid, B H 4 > workgroups - were
+        // built (mb_unit_cross<Q, 2>) and measured: the 144 registers of a half's keys / values push the whole kernel into scratch (463 spilled
+        // registers; 5 rows 0.67 -> 0.78 ms, 8 rows 0.92 -> 1.06 ms per step), the half itself took 22 us against 2 x 9.8 for two rounds of quarters.)
         for (int u = wg; u < B * H * 4; u += nwg) {
             const int bh = u >> 2;
-            mb_cross_regs CR;       // (asked for here: earlier - across the cross-query products - the 72 registers cost those products 2 us and won 0.8)
-            mb_cross_load(A, l, bh / H, bh % H, u & 3, tid, CR);
-            mb_unit_cross<Q>(A, c, area, l, bh / H, bh % H, u & 3, tid, tw, CR);
+            mb_cross_regs<4> CR;    // (asked for here: earlier - across the cross-query products - the 72 registers cost those products 2 us and won 0.8)
+            mb_cross_load<4>(A, l, bh / H, bh % H, u & 3, tid, CR);
+            mb_unit_cross<Q, 4>(A, c, area, l, bh / H, bh % H, u & 3, tid, tw, CR);
         }
         MB_T(8);
         // ---------------- P6: out-projection + residual ----------------
@@ -1265,15 +1332,38 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     if (wg == 0 && tid == 0) ((GAS unsigned *) A->status)[1] = seq;       // this launch ran (the host accepts a step only with its own number here)
 }
 
-__global__ __launch_bounds__(MB_THREADS) void k_decode_rows(const wa_rows_args A) {
-    const mb_kargs Ap = (mb_kargs) __builtin_amdgcn_kernarg_segment_ptr();
-    if (A.d <= 768) mb_body<12, false>(Ap); else if (A.d <= 1024) mb_body<16, false>(Ap); else mb_body<20, false>(Ap);
+// One kernel per LayerNorm width (elements per lane: 12 for d <= 768, 16 for <= 1024, 20 for <= 1280) and weight format, each in a translation unit
+// of its own (the Makefile compiles this file three times, -DWA_ROWS_NP=12 / 16 / 20): with every width in ONE kernel the register allocation was
+// the widest variant's for all of them (1525 spilled SGPRs and 32-113 VGPRs against 503 and 18 for the d <= 768 kernel alone).
+#ifndef WA_ROWS_NP
+#define WA_ROWS_NP 12
+#endif
+#define MB_CAT_(a, b) a##b
+#define MB_CAT(a, b) MB_CAT_(a, b)
+__global__ __launch_bounds__(MB_THREADS) void MB_CAT(k_decode_rows_np, WA_ROWS_NP)(const wa_rows_args A) {
+    mb_body<WA_ROWS_NP, false>((mb_kargs) __builtin_amdgcn_kernarg_segment_ptr());
 }
 // the same step for a quantised model (Q5_0 / Q8_0 files): a kernel of its own, so that the F16 kernel's code and registers stay as they are
-__global__ __launch_bounds__(MB_THREADS) void k_decode_rows_q(const wa_rows_args A) {
-    const mb_kargs Ap = (mb_kargs) __builtin_amdgcn_kernarg_segment_ptr();
-    if (A.d <= 768) mb_body<12, true>(Ap); else if (A.d <= 1024) mb_body<16, true>(Ap); else mb_body<20, true>(Ap);
+__global__ __launch_bounds__(MB_THREADS) void MB_CAT(k_decode_rows_q_np, WA_ROWS_NP)(const wa_rows_args A) {
+    mb_body<WA_ROWS_NP, true>((mb_kargs) __builtin_amdgcn_kernarg_segment_ptr());
 }
+bool MB_CAT(wa_rows_launch_np, WA_ROWS_NP)(hipStream_t s, const wa_rows_args & a, int n_wg, size_t lds) {
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    static bool attr_set[64] = {};
+    if (!attr_set[dev & 63]) {
+        if (hipFuncSetAttribute((const void *) MB_CAT(k_decode_rows_np, WA_ROWS_NP), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *) MB_CAT(k_decode_rows_q_np, WA_ROWS_NP), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set[dev & 63] = true;
+    }
+    if (a.quant) hipLaunchKernelGGL(MB_CAT(k_decode_rows_q_np, WA_ROWS_NP), dim3(n_wg), dim3(MB_THREADS), lds, s, a);
+    else         hipLaunchKernelGGL(MB_CAT(k_decode_rows_np, WA_ROWS_NP), dim3(n_wg), dim3(MB_THREADS), lds, s, a);
+    return hipGetLastError() == hipSuccess;
+}
+
+#if WA_ROWS_NP == 12      // the host side once
+bool wa_rows_launch_np16(hipStream_t s, const wa_rows_args & a, int n_wg, size_t lds);
+bool wa_rows_launch_np20(hipStream_t s, const wa_rows_args & a, int n_wg, size_t lds);
 
 size_t wa_rows_lds_bytes(int d, int B, int n_wg, int quant, int * slot_bytes) {
     if (B < 1 || B > WA_ROWS_MAX || d < 64 || d > WA_MEGA_MAX_D || (d & 127) != 0 || n_wg < 1) return 0;
@@ -1315,15 +1405,8 @@ bool wa_launch_decode_rows(hipStream_t s, const wa_rows_args & a, int n_wg) {
     int slot = 0;
     const size_t lds = wa_rows_lds_bytes(a.d, a.B, n_wg, a.quant, &slot);
     if (lds == 0 || slot != a.slot_bytes) return false;
-    int dev = 0;
-    (void) hipGetDevice(&dev);
-    static bool attr_set[64] = {};
-    if (!attr_set[dev & 63]) {
-        if (hipFuncSetAttribute((const void *) k_decode_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *) k_decode_rows_q, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-        attr_set[dev & 63] = true;
-    }
-    if (a.quant) hipLaunchKernelGGL(k_decode_rows_q, dim3(n_wg), dim3(MB_THREADS), lds, s, a);
-    else         hipLaunchKernelGGL(k_decode_rows, dim3(n_wg), dim3(MB_THREADS), lds, s, a);
-    return hipGetLastError() == hipSuccess;
+    if (a.d <= 768)  return wa_rows_launch_np12(s, a, n_wg, lds);
+    if (a.d <= 1024) return wa_rows_launch_np16(s, a, n_wg, lds);
+    return wa_rows_launch_np20(s, a, n_wg, lds);
 }
+#endif
