@@ -326,12 +326,12 @@ def main():
             # HBM bytes per launch from the PMC counters (collected off-line with tools/profile_gpu.sh, one counter per pass, summary
             # committed under profiles/): 2 x FETCH_SIZE (gfx950 tallies 128-byte reads at 64 bytes) + WRITE_SIZE, in KiB
             traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r02_decode_step_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r03_decode_step_pmc.json")
             if args.model == "small" and os.path.exists(pmc) and lib.whisper_amd_mega_enabled(st.ptr):
                 try:
                     pj = json.load(open(pmc))
                     traffic = int((2 * pj["FETCH_SIZE_KB_per_launch"] + pj["WRITE_SIZE_KB_per_launch"]) * 1024)
-                    traffic_src = "profiles/r02_decode_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2) - collected off-line, not in this run"
+                    traffic_src = "profiles/r03_decode_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x 2) - collected off-line, not in this run"
                 except (KeyError, ValueError):
                     traffic, traffic_src = None, None
             kname = ("k_decode_mega: the whole single-token decoder pass as ONE persistent launch (256 workgroups, granule hand-offs), n_past=64"

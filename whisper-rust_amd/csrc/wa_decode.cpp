@@ -463,6 +463,7 @@ struct wa_batcher {
     struct req { whisper_state * st; int token, pos, n_kv, kv_head; int result; const float * row; };      // result: 0 pending, 1 served (`row`: its logits in the pass's staging buffer), -1 not served
     std::vector<req *> waiting;
     long n_steps = 0, n_rows = 0, n_one_launch = 0;       // passes, the token rows they served, passes that were ONE launch (wa_rows.hip)
+    int64_t t_pass_us = 0, t_gap_us = 0, t_last_end = 0;   // (WHISPER_AMD_BATCH_TRACE) time inside the passes / between the end of one and the start of the next
     // the pass for B rows as a hipGraph (122 launches for ggml-small): captured on first use, replayed while T and the cell count stay
     hipGraphExec_t graph[WA_MAX_DECODERS + 1] = {};
     int graph_T[WA_MAX_DECODERS + 1] = {}; uint32_t graph_kv[WA_MAX_DECODERS + 1] = {};
@@ -481,7 +482,7 @@ wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
         if (!ctx.batcher_cache.empty()) { b = (wa_batcher *) ctx.batcher_cache.back(); ctx.batcher_cache.pop_back(); }
     }
     if (b) {
-        b->n_members = n_members; b->waiting.clear(); b->n_steps = b->n_rows = b->n_one_launch = 0;
+        b->n_members = n_members; b->waiting.clear(); b->n_steps = b->n_rows = b->n_one_launch = 0; b->t_pass_us = b->t_gap_us = b->t_last_end = 0;
         return b;
     }
     b = new wa_batcher();
@@ -530,6 +531,8 @@ static void batcher_run(wa_batcher & b) {
         else r->result = -1;                        // decoded by its own thread the ordinary way
     }
     const int B = (int) run.size();
+    const int64_t t_begin = wa_time_us();
+    if (b.t_last_end) b.t_gap_us += t_begin - b.t_last_end;
     bool ok = WA_HIP_OK(hipSetDevice(ctx.device));
     // (tests: a pass whose launch failed must not hand out the stale contents of the staging buffer - every member then decodes alone)
     static const bool test_fail = getenv("WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH") != nullptr;
@@ -589,6 +592,10 @@ static void batcher_run(wa_batcher & b) {
     // requests): eight 200 KB copies one after the other cost the group 0.15 ms per pass
     for (int i = 0; i < B; ++i) { run[i]->row = bs.h_logits_pinned + (size_t) i * n_vocab; run[i]->result = ok ? 1 : -1; }
     b.n_steps += 1; b.n_rows += B;
+    b.t_last_end = wa_time_us();
+    b.t_pass_us += b.t_last_end - t_begin;
+    static const bool trace = getenv("WHISPER_AMD_BATCH_TRACE") != nullptr;
+    if (trace && (b.n_steps % 100) == 0) fprintf(stderr, "[batcher] %ld passes: %.3f ms in a pass, %.3f ms between passes (mean)\n", b.n_steps, 1e-3 * b.t_pass_us / b.n_steps, 1e-3 * b.t_gap_us / b.n_steps);
 }
 
 // a member's single-token step: 1 = logits delivered into st.logits, 0 = not served (the caller decodes it itself)

@@ -26,6 +26,14 @@ struct wa_rows_row {                 // where ONE token row's state lives (layer
     const int8_t * mask;             // [n_kv] 1 = cell hidden from this row (beams share cells by sequence id); null: every cell < n_kv visible
     int n_kv, kv_head;               // cells attended over; the cell this row's new key / value go to
     int token, pos;
+    // next-token prediction for lock-step members that decode greedily (wa_decode.cpp: the run-ahead batcher; as wa_mega_args): with `smask` set
+    // the launch leaves per-workgroup candidate records of the row's logits under the reference's logit rules (approximated: the host verifies
+    // every token); with spec != 0 the row's token is picked from the records and state its previous pass left, not taken from `token`.
+    int spec;
+    const unsigned * rec_in; unsigned * rec_out;      // [n_workgroups][8]: {max text logit, id, max timestamp logit, id, sum exp(ts - max ts)}
+    const int * ps_in; int * ps_out;                  // {last token, token before it (-1: none), seek_delta, has_ts}; ps_out[4] = the token this launch decoded
+    const unsigned * smask;                           // bit i set: token i is suppressed for the row's whole call; null: no records
+    int s_last, s_penult, s_seek_delta, s_has_ts;     // spec == 0: the state after `token`, from the host
 };
 
 struct wa_rows_args {
@@ -43,6 +51,7 @@ struct wa_rows_args {
     float * dbg;
     float kq_scale; unsigned seq;
     int B, slot_bytes;
+    int token_beg, token_eot;                           // (records) first timestamp token, end-of-text token
     int n_out, out_row[WA_ROWS_MAX];                    // token rows whose logits are wanted (the reference flags batch.logits rows): logits row m = token row out_row[m]
     wa_rows_row rows[WA_ROWS_MAX];
 };

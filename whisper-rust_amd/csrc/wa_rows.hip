@@ -318,7 +318,7 @@ __device__ __forceinline__ double mb_seq_sum(const float (&xv)[NP], int d, bool 
 }
 template <int NP, bool Q = false>         // Q: the normalised row leaves as Q8_0 (the next product's operand), not as F16
 __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_row /* null: embeddings */, const float * lnp /* LDS: gamma | beta, each d floats in whole KB */, const float * gw_g, const float * gb_g /* global, when non-null */,
-                                          int b, int lane, wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code) {
+                                          int b, int lane, wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code, int token = 0) {
     const int d = A->d;
     float xv[NP];
     if (edge_row) {
@@ -329,13 +329,13 @@ __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_ro
     } else {                    // k_dec_embed: token embedding + positional embedding
         const gcf pe = (gcf) A->pe + (size_t) A->rows[b].pos * d;
         if constexpr (!Q) {
-            const gch te = (gch) A->te + (size_t) A->rows[b].token * d;
+            const gch te = (gch) A->te + (size_t) token * d;
 #pragma unroll
             for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : d - 1; const float e = h2f(te[ic]) + pe[ic]; xv[k] = i < d ? e : 0.0f; }
         } else {                // k_dec_embed_q: the row dequantised (q * d, ggml-quants.c)
             const int nb = d >> 5;
-            const GAS int8_t * tq = (const GAS int8_t *) A->te + (size_t) A->rows[b].token * 8 * nb * 4;
-            const gcf td = (gcf) A->te_d + (size_t) A->rows[b].token * nb;
+            const GAS int8_t * tq = (const GAS int8_t *) A->te + (size_t) token * 8 * nb * 4;
+            const gcf td = (gcf) A->te_d + (size_t) token * nb;
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int i = lane + 64 * k, ic = i < d ? i : d - 1, bb = ic >> 5, el = ic & 31;
@@ -906,7 +906,7 @@ __device__ __forceinline__ void mb_te_first(mb_kargs A, bool quant, unsigned (&b
 }
 
 template <int BT>
-__device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /* rows of xs = logits rows */, int lane, int wave, unsigned (&pfa)[48]) {
+__device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /* rows of xs = logits rows */, int lane, int wave, unsigned (&pfa)[48], float * lg /* LDS [BT][256] or null */) {
     const int d = A->d, ns = d >> 5, nbat = (ns + 23) / 24, n_vocab = A->n_vocab;
     const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
     GAS float * logits = (GAS float *) A->logits;
@@ -960,6 +960,7 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
                 }
                 const float r = (t[0] + t[1]) + (t[2] + t[3]);
                 if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = r;
+                if (lg && u == 0 && j < 4) lg[m * 256 + (8 * j + wave) * 8 + (lane >> 3)] = r;
             }
         }
     };
@@ -976,7 +977,7 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
 // the same for a quantised token embedding: a row = 8 lanes x (quads [nb], F32 block scales [nb]) streamed in pieces of 24 blocks; the token
 // rows' final LayerNorm outputs sit in `xop` quantised (mb_ln_row<.., true>)
 template <int BT>
-__device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xop, size_t op_bytes, int B, int lane, int wave, unsigned (&pfa)[48]) {
+__device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xop, size_t op_bytes, int B, int lane, int wave, unsigned (&pfa)[48], float * lg) {
     const int d = A->d, nb = d >> 5, nbat = (nb + 23) / 24, n_vocab = A->n_vocab;
     const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
     GAS float * logits = (GAS float *) A->logits;
@@ -1017,6 +1018,7 @@ __device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xo
                 float v = acc[m];
                 v = v + dpp_f32<0x104>(v); v = v + dpp_f32<0x102>(v); v = v + dpp_f32<0x101>(v);
                 if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = v;
+                if (lg && u == 0 && j < 4) lg[m * 256 + (8 * j + wave) * 8 + (lane >> 3)] = v;
             }
         }
     };
@@ -1028,6 +1030,103 @@ __device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xo
         if (it + 2 < n_items) load(it + 2, pfa);
         one(it + 1, pfb);
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// next-token prediction per row (wa_mega.hip: mg_pick / mg_final's records; the host re-derives every token from the logits with the reference's
+// rules - this arithmetic is a prediction only).  mb_pick: one wave, the row's token and the sampling state after it -> pk[0..4].
+// -------------------------------------------------------------------------------------------------
+struct mb_best { float v; int i; };
+__device__ __forceinline__ void mb_best_merge(mb_best & a, float v, int i) { if (v > a.v || (v == a.v && i < a.i)) { a.v = v; a.i = i; } }
+__device__ __forceinline__ void mb_best_wave(mb_best & a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float v = __shfl_xor(a.v, o, WAVE); const int i = __shfl_xor(a.i, o, WAVE); mb_best_merge(a, v, i); }
+}
+__device__ __forceinline__ void mb_pick(mb_kargs A, int b, int lane, int * pk, int n_rec) {
+    int token = A->rows[b].token, last = A->rows[b].s_last, penult = A->rows[b].s_penult, seek_delta = A->rows[b].s_seek_delta, has_ts = A->rows[b].s_has_ts;
+    if (A->rows[b].spec) {
+        const GAS int * ps = (const GAS int *) A->rows[b].ps_in;
+        const GAS unsigned * rec = (const GAS unsigned *) A->rows[b].rec_in;
+        penult = ps[0]; seek_delta = ps[2]; has_ts = ps[3];
+        mb_best bt = { -INFINITY, 0x7fffffff }, bs = { -INFINITY, 0x7fffffff };
+        u32x4 ra[4]; unsigned rb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {           // every record (n_rec <= 256: four per lane) in ONE round of loads
+            const int g = lane + 64 * j, gg = g < n_rec ? g : 0;
+            ra[j] = *(const GAS u32x4 *) (rec + gg * 8); rb[j] = rec[gg * 8 + 4];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (lane + 64 * j < n_rec) {
+            mb_best_merge(bt, __uint_as_float(ra[j].x), (int) ra[j].y);
+            mb_best_merge(bs, __uint_as_float(ra[j].z), (int) ra[j].w);
+        }
+        mb_best_wave(bt); mb_best_wave(bs);
+        float sm = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (lane + 64 * j < n_rec) {
+            const float m = __uint_as_float(ra[j].z);
+            if (m > -INFINITY) sm += __uint_as_float(rb[j]) * __expf(m - bs.v);
+        }
+        sm = wave_sum(sm);
+        // whisper.cpp:6309-6333: timestamp mass above every text token => a timestamp; else the arg-max of everything allowed
+        if (!(bs.v > -INFINITY)) token = bt.v > -INFINITY ? bt.i : 0;
+        else if (!(bt.v > -INFINITY)) token = bs.i;
+        else if (__logf(sm) + bs.v > bt.v) token = bs.i;
+        else token = bs.v > bt.v ? bs.i : bt.i;
+        last = token;
+        if (token > A->token_beg) { seek_delta = 2 * (token - A->token_beg); has_ts = 1; }
+    }
+    if (lane == 0) {
+        pk[0] = token; pk[1] = last; pk[2] = penult; pk[3] = seek_delta; pk[4] = has_ts;
+        if (blockIdx.x == 0 && A->rows[b].ps_out) {
+            GAS int * po = (GAS int *) A->rows[b].ps_out;
+            po[0] = last; po[1] = penult; po[2] = seek_delta; po[3] = has_ts; po[4] = token;
+        }
+    }
+}
+// candidate records of logits row m (token row br) from this workgroup's share of the logits, kept in LDS by mb_logits (lg [BT][256]); all threads
+__device__ __forceinline__ void mb_record(mb_kargs A, int br, const float * lg_m, const int * pk, unsigned * scratch /* LDS [8][8] */, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab, beg = A->token_beg, eot = A->token_eot;
+    const GAS unsigned * smask = (const GAS unsigned *) A->rows[br].smask;
+    const int st_last = pk[1], st_penult = pk[2], st_seek = pk[3], st_has = pk[4];
+    const bool last_ts = st_last >= beg, penult_ts = st_penult < 0 || st_penult >= beg;
+    const bool no_ts = last_ts && penult_ts, no_text = last_ts && !penult_ts;
+    const int ts_min = st_has ? beg + st_seek / 2 : beg;
+    mb_best bt = { -INFINITY, 0x7fffffff }, bs = { -INFINITY, 0x7fffffff };
+    float s_ts = 0.0f;
+    if (tid < 256) {        // local row li = (8 j + wave') 8 + r8  <->  vocabulary row 8 (wg + nwg (wave' + 8 j)) + r8
+        const int li = tid, row = 8 * (wg + nwg * (((li >> 3) & 7) + 8 * (li >> 6))) + (li & 7);
+        if (row < n_vocab) {
+            const float r = lg_m[li];
+            const unsigned mw = smask[row >> 5];
+            if (!((mw >> (row & 31)) & 1u)) {
+                if (row >= beg) { if (!no_ts && row >= ts_min) { bs.v = r; bs.i = row; s_ts = 1.0f; } }
+                else if (!(no_text && row < eot)) { bt.v = r; bt.i = row; }
+            }
+        }
+    }
+    const float m_loc = bs.v;
+    mb_best_wave(bt); mb_best_wave(bs);
+    float sw = m_loc > -INFINITY ? s_ts * __expf(m_loc - bs.v) : 0.0f;
+    sw = wave_sum(sw);
+    if (lane == 0) { scratch[wave * 8 + 0] = __float_as_uint(bt.v); scratch[wave * 8 + 1] = (unsigned) bt.i; scratch[wave * 8 + 2] = __float_as_uint(bs.v);
+                     scratch[wave * 8 + 3] = (unsigned) bs.i; scratch[wave * 8 + 4] = __float_as_uint(sw); }
+    mb_barrier();
+    if (wave == 0) {
+        mb_best t2 = { -INFINITY, 0x7fffffff }, s2 = { -INFINITY, 0x7fffffff };
+        float sl = 0.0f, ml = -INFINITY;
+        if (lane < MB_NW) { t2.v = __uint_as_float(scratch[lane * 8 + 0]); t2.i = (int) scratch[lane * 8 + 1]; s2.v = __uint_as_float(scratch[lane * 8 + 2]); s2.i = (int) scratch[lane * 8 + 3];
+                            sl = __uint_as_float(scratch[lane * 8 + 4]); ml = s2.v; }
+        mb_best_wave(t2); mb_best_wave(s2);
+        float sg = ml > -INFINITY ? sl * __expf(ml - s2.v) : 0.0f;
+        sg = wave_sum(sg);
+        if (lane == 0) {
+            GAS unsigned * ro = (GAS unsigned *) A->rows[br].rec_out + (size_t) wg * 8;
+            ro[0] = __float_as_uint(t2.v); ro[1] = (unsigned) t2.i; ro[2] = __float_as_uint(s2.v); ro[3] = (unsigned) s2.i; ro[4] = __float_as_uint(sg);
+        }
+    }
+    mb_barrier();
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1047,15 +1146,17 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     const int d = A->d, L = A->n_layer, B = A->B, H = A->n_head, d4 = 4 * d, RG = A->row_gr;
     const mb_layers Ly = (mb_layers) A->layers;
 
-    // LDS: xres [8][8] f32 | fc1x [8][32] f32 (quantised models: a block of FC1 outputs) | lnp: gamma | beta of the next LayerNorm | xinB: B operand rows
+    // LDS: xres [8][8] f32 | fc1x [8][32] f32 (quantised models: a block of FC1 outputs) | pk, record scratch | lnp: gamma | beta of the next LayerNorm | xinB: B operand rows
     // of length d (LayerNorm outputs) | area: B operand rows of length 4d (gathered inputs) / attention scratch | slot 0 | slot 1 (weight rows, then - in
     // the last KB - the rows' bias and scale).  An operand row is [len] F16, or - quantised models - Q8_0 in the order of mb_dotq8.
     float  * xres = (float *) smem;
     float  * fc1x = (float *) (smem + 256);
-    float  * lnp  = (float *) (smem + 1280);
+    int    * pk   = (int *) (smem + 1280);            // [8][8] per token row: its token and the sampling state after it (mb_pick)
+    unsigned * rscr = (unsigned *) (smem + 1536);     // [8][8] scratch of mb_record
+    float  * lnp  = (float *) (smem + 1792);
     const size_t lnp_bytes = 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023);      // (an LDS-DMA instruction writes a whole KB: each vector ends on one)
     const size_t opB = Q ? mq_row_bytes(d >> 5) : (size_t) d * 2, op4 = Q ? mq_row_bytes(d4 >> 5) : (size_t) d4 * 2;      // bytes of an operand row
-    unsigned char * xinB = smem + 1280 + lnp_bytes;
+    unsigned char * xinB = smem + 1792 + lnp_bytes;
     const size_t xinB_bytes = ((size_t) B * opB + 255) & ~(size_t) 255;
     unsigned char * area = xinB + xinB_bytes;
     unsigned char * xin = area;
@@ -1169,6 +1270,8 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     const size_t opD = Q ? opB : (size_t) d4 * 2;      // pitch of the d-long operand rows in `xin`
 
     if (wave == MB_NW - 1 && L > 0) request(0, 0, 0, 0);
+    if (wave < B) mb_pick(A, wave, lane, pk + 8 * wave, min(nwg, 256));      // the rows' tokens: given, or picked from the records their previous passes left
+    mb_barrier();
 #define MB_T(k) do { mb_trace(A, tw, l * 32 + (k)); mb_trace(A, tid == 0 && l == MB_TRACE_LAYER, 8192 + wg * 16 + (k)); } while (0)      /* every workgroup at ONE layer */
     for (int l = 0; l < L; ++l) {
         const __attribute__((address_space(4))) wa_mega_layer & Y = Ly[l];
@@ -1176,7 +1279,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_CHAOS_AT(27u);
         // ---------------- P1: LayerNorm + q|k|v ----------------
         if (wave < B) mb_ln_row<NP, Q>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, l == 0 ? Y.ln1_w : nullptr, l == 0 ? Y.ln1_b : nullptr,
-                                       wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), xres + wave * 8, row_d, r_d, 100u + l);
+                                       wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), xres + wave * 8, row_d, r_d, 100u + l, pk[8 * wave]);
         MB_T(1);
         run_phase(l, 0, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
             gu64 * eq = mb_edge(A, l, E_QKV);
@@ -1318,15 +1421,25 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     if (wave < n_out) {
         const int br = A->out_row[wave];
         mb_ln_row<NP, Q>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, lnp, L > 0 ? nullptr : A->lnf_w, L > 0 ? nullptr : A->lnf_b, br, lane,
-                         (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 3000u);
+                         (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 3000u, pk[8 * br]);
     }
+    bool want_rec = false;
+    for (int m = 0; m < n_out; ++m) want_rec = want_rec || A->rows[A->out_row[m]].smask != nullptr;
+    float * lg = want_rec ? (float *) area : nullptr;            // (the gathered-inputs area holds nothing any more)
     mb_barrier();
     if constexpr (Q) {
-        if (n_out <= 2) mb_logits_q<2>(A, xinB, opB, n_out, lane, wave, pf0); else if (n_out <= 4) mb_logits_q<4>(A, xinB, opB, n_out, lane, wave, pf0);
-        else if (n_out <= 5) mb_logits_q<5>(A, xinB, opB, n_out, lane, wave, pf0); else mb_logits_q<8>(A, xinB, opB, n_out, lane, wave, pf0);
+        if (n_out <= 2) mb_logits_q<2>(A, xinB, opB, n_out, lane, wave, pf0, lg); else if (n_out <= 4) mb_logits_q<4>(A, xinB, opB, n_out, lane, wave, pf0, lg);
+        else if (n_out <= 5) mb_logits_q<5>(A, xinB, opB, n_out, lane, wave, pf0, lg); else mb_logits_q<8>(A, xinB, opB, n_out, lane, wave, pf0, lg);
     } else {
-        if (n_out <= 2) mb_logits<2>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0); else if (n_out <= 4) mb_logits<4>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0);
-        else if (n_out <= 5) mb_logits<5>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0); else mb_logits<8>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0);
+        if (n_out <= 2) mb_logits<2>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg); else if (n_out <= 4) mb_logits<4>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg);
+        else if (n_out <= 5) mb_logits<5>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg); else mb_logits<8>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg);
+    }
+    if (want_rec) {          // candidate records of every row that asked for them (the next pass of its chunk picks its token from them)
+        mb_barrier();
+        for (int m = 0; m < n_out; ++m) {
+            const int br = A->out_row[m];
+            if (A->rows[br].smask) mb_record(A, br, lg + m * 256, pk + 8 * br, rscr, tid);
+        }
     }
     { const int l = L; MB_T(1); }
     if (wg == 0 && tid == 0) ((GAS unsigned *) A->status)[1] = seq;       // this launch ran (the host accepts a step only with its own number here)
@@ -1372,7 +1485,7 @@ size_t wa_rows_lds_bytes(int d, int B, int n_wg, int quant, int * slot_bytes) {
     size_t area = (size_t) B * op4;
     if (area < MB_ATT_BYTES) area = MB_ATT_BYTES;
     area = (area + 255) & ~(size_t) 255;
-    const size_t fixed = 1280 + 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023) + xinB_bytes + area;
+    const size_t fixed = 1792 + 2 * (((size_t) d * 4 + 1023) & ~(size_t) 1023) + xinB_bytes + area;
     auto rpw = [&](int N) { const int r = (N + n_wg - 1) / n_wg; return (r + 1) & ~1; };
     if (rpw(d) > 8) return 0;                       // (xres holds 8 residual values per token row)
     if (quant && (4 * d) / 32 > n_wg) return 0;     // (whole-block ownership of the first MLP product: one workgroup per block)
