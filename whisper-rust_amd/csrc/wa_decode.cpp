@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <mutex>
+#include <deque>
 #include <condition_variable>
 #include <vector>
 #include <cstring>
@@ -289,7 +290,9 @@ static int mega_step(whisper_context & ctx, whisper_state & st, int token, int p
     hipStream_t s = st.stream;
     unsigned status = 0, echo = 0;
     {
-        std::lock_guard<std::mutex> lk(mega_slot(ctx.device));
+        // (a member of a lock-step group never WAITS for the slot: its group may hold it for the others' run-ahead windows, and they wait for this member)
+        std::unique_lock<std::mutex> lk(mega_slot(ctx.device), std::defer_lock);
+        if (st.batcher) { if (!lk.try_lock()) return 0; } else lk.lock();
         if (!wa_launch_decode_mega(s, a, std::min(ctx.model.n_cu, 256))) { st.mega_enabled = false; return 0; }
         (void) hipMemcpyAsync(st.h_logits_pinned, st.d_mega_out, ((size_t) n_vocab + 3) * sizeof(float), hipMemcpyDeviceToHost, s);
         if (!WA_HIP_OK(hipStreamSynchronize(s))) { st.mega_enabled = false; return 0; }
@@ -331,7 +334,7 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
     a.kv_layer_stride = (unsigned long long) kv_size * hp.n_text_state;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * cross_tpad * 64; a.cross_tpad = cross_tpad; a.T = T;
     a.granules = bst.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = bst.d_rows_cgr;
-    a.logits = bst.d_logits; a.status = bst.d_rows_status; a.dbg = nullptr;
+    a.logits = bst.d_logits; a.status = bst.d_rows_status; a.row_status = bst.d_rows_status + 4; a.dbg = nullptr;
     a.kq_scale = pow(float(64), -0.25);
     a.B = B;
     for (int i = 0; i < B; ++i) a.rows[i] = rows[i];
@@ -343,12 +346,14 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
     unsigned * h_status = (unsigned *) (bst.h_logits_pinned + (size_t) WA_MAX_DECODERS * hp.n_vocab);      // (the staging buffer has 64 spare words)
     std::unique_lock<std::mutex> lk(mega_slot(ctx.device), std::defer_lock);
     if (wait_slot) lk.lock(); else if (!lk.try_lock()) return 0;
+    (void) hipMemsetAsync(bst.d_rows_status + 4, 0, WA_ROWS_MAX * sizeof(unsigned), s);
     if (!wa_launch_decode_rows(s, a, n_wg)) { bst.rows_enabled = false; return 0; }
     (void) hipMemcpyAsync(bst.h_logits_pinned, bst.d_logits, (size_t) n_out * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
-    (void) hipMemcpyAsync(h_status, bst.d_rows_status, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
+    (void) hipMemcpyAsync(h_status, bst.d_rows_status, 12 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
     if (!WA_HIP_OK(hipStreamSynchronize(s))) { bst.rows_enabled = false; return 0; }
     lk.unlock();
-    const unsigned status = h_status[0], echo = h_status[1];
+    unsigned status = h_status[0]; const unsigned echo = h_status[1];
+    for (int i = 0; i < B && status == 0; ++i) if (h_status[4 + i] != 0) status = WA_MEGA_REDO;      // (one caller for all rows here: any row to be redone sends the pass back)
     if (status == 0 && echo == a.seq) { bst.n_rows_steps += 1; return 1; }
     bst.n_rows_fallback += 1;
     (void) hipMemsetAsync(bst.d_rows_status, 0, sizeof(unsigned), s);
@@ -366,7 +371,14 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
 // in flight are discarded and the step is redone with the right token.  Launch k writes output / record / state buffer
 // k & 1 and reads buffer (k - 1) & 1; at most launches k and k + 1 are in flight while the host works on logits k - 1...k.
 // -------------------------------------------------------------------------------------------------
+static bool bspec_begin(wa_batcher & b, whisper_state & st, const std::vector<uint32_t> & bits);
+static bool bspec_launch(wa_batcher & b, whisper_state & st, int k, int pos, int token, const wa_spec_state & after);
+static int  bspec_wait(wa_batcher & b, whisper_state & st, int * token_used);
+static void bspec_drain(wa_batcher & b, whisper_state & st);
+static void bspec_end(wa_batcher & b, whisper_state & st);
+
 bool wa_spec_begin(whisper_context & ctx, whisper_state & st, const std::vector<uint32_t> & bits) {
+    if (st.batcher) return bspec_begin(*st.batcher, st, bits);        // a member of a lock-step group: its window runs on the group's passes
     if (!st.mega_enabled || st.mega_pause > 0 || bits.size() > (size_t) ctx.model.hp.n_vocab / 32 + 2) return false;
     if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;
     if (!st.copy_stream) {      // first use on this state
@@ -392,6 +404,7 @@ bool wa_spec_begin(whisper_context & ctx, whisper_state & st, const std::vector<
 }
 
 void wa_spec_end(whisper_context & ctx, whisper_state & st) {
+    if (st.batcher) { bspec_end(*st.batcher, st); return; }
     (void) hipStreamSynchronize(st.stream);
     if (st.copy_stream) (void) hipStreamSynchronize(st.copy_stream);
     (void) hipMemsetAsync(st.d_mega_smask, 0, ((size_t) st.ctx->model.hp.n_vocab / 32 + 2) * sizeof(uint32_t), st.stream);   // plain steps use no mask
@@ -400,6 +413,7 @@ void wa_spec_end(whisper_context & ctx, whisper_state & st) {
 }
 
 bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, int token, const wa_spec_state & after) {
+    if (st.batcher) return bspec_launch(*st.batcher, st, k, pos, token, after);
     wa_mega_args a;
     if (!mega_args(ctx, st, a, token < 0 ? 0 : token, pos, pos + 1, pos)) return false;       // greedy steady state: cell == position
     const int b = k & 1;
@@ -418,8 +432,13 @@ bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, i
 }
 
 int wa_spec_wait(whisper_context & ctx, whisper_state & st, int k, int * token_used) {
-    const int b = k & 1, n_vocab = ctx.model.hp.n_vocab;
     const int64_t t0 = wa_time_us();
+    if (st.batcher) {
+        const int rc = bspec_wait(*st.batcher, st, token_used);
+        st.t_decode_us += wa_time_us() - t0; st.n_decode++;
+        return rc;
+    }
+    const int b = k & 1, n_vocab = ctx.model.hp.n_vocab;
     if (!WA_HIP_OK(hipEventSynchronize(st.ev_c[b]))) { st.mega_enabled = false; return -1; }
     unsigned status = ((const unsigned *) st.h_spec[b])[n_vocab];
     if (status == 0 && ((const unsigned *) st.h_spec[b])[n_vocab + 2] != st.spec_seq[b]) status = 9999u;      // the launch never ran: not this step's logits
@@ -440,6 +459,7 @@ int wa_spec_wait(whisper_context & ctx, whisper_state & st, int k, int * token_u
 }
 
 void wa_spec_drain(whisper_context &, whisper_state & st) {
+    if (st.batcher) { bspec_drain(*st.batcher, st); return; }
     (void) hipStreamSynchronize(st.stream);
     (void) hipStreamSynchronize(st.copy_stream);
 }
@@ -453,6 +473,25 @@ void wa_spec_drain(whisper_context &, whisper_state & st) {
 // attending over its own state's cells and encoder K / V (wa_rowptr) - and every member gets its logits row back.  Nothing else
 // changes: sampling, KV bookkeeping and results are each member's own, bit-identical to a solo run (same kernels, same order).
 // -------------------------------------------------------------------------------------------------
+// A member's request for one decoder step.  Plain: (token, pos, cells) given, the member waits for its logits at once.  Run-ahead (greedy members,
+// wa_spec_* below): step k of the member's window at position pos = cell pos, its token either given or - token < 0 - picked by the device from the
+// candidate records the member's previous pass left (wa_rows.hip: mb_pick); the member asks for step k + 1 before it waits for step k, so pass k + 1
+// runs while the members apply the reference's sampling rules to the logits of pass k.
+struct wa_breq {
+    int k = 0, token = 0, pos = 0, n_kv = 0, kv_head = 0;
+    bool ahead = false;                             // a run-ahead request (leaves records; wa_breq::token < 0: picks its token)
+    wa_spec_state after = { 0, -1, 0, 0 };
+    long pass = -1; int row = -1;                   // once launched: the pass and its row
+    int result = 0;                                 // 0 pending, 1 launched / served, -1 not served (the member decodes alone)
+};
+struct wa_bslot {                                   // a member of the group
+    whisper_state * st = nullptr;
+    std::deque<wa_breq> q;                          // requests not yet collected, in step order (<= 2)
+    unsigned * d_rec[2] = { nullptr, nullptr }; int * d_ps[2] = { nullptr, nullptr }; unsigned * d_smask = nullptr;      // run-ahead: by the parity of the member's step
+    bool ahead = false;                             // inside a run-ahead window
+};
+struct wa_bpass { unsigned seq = 0; int B = 0, parity = 0; bool launched = false, done = false, ok = false; unsigned status = 0; };
+
 struct wa_batcher {
     whisper_context * ctx = nullptr;
     whisper_state * bst = nullptr;                  // private state: activations, scratch and stream of the batched pass
@@ -460,10 +499,19 @@ struct wa_batcher {
     std::mutex m;
     std::condition_variable cv;
     int n_members = 0;                              // threads that may still submit
-    struct req { whisper_state * st; int token, pos, n_kv, kv_head; int result; const float * row; };      // result: 0 pending, 1 served (`row`: its logits in the pass's staging buffer), -1 not served
-    std::vector<req *> waiting;
+    wa_bslot slots[WA_MAX_DECODERS];
     long n_steps = 0, n_rows = 0, n_one_launch = 0;       // passes, the token rows they served, passes that were ONE launch (wa_rows.hip)
-    int64_t t_pass_us = 0, t_gap_us = 0, t_last_end = 0;   // (WHISPER_AMD_BATCH_TRACE) time inside the passes / between the end of one and the start of the next
+    int64_t t_pass_us = 0, t_gap_us = 0, t_last_end = 0;   // (WHISPER_AMD_BATCH_TRACE) time inside the synchronous passes / between them
+    // asynchronous passes (the one-launch form): two sets of output buffers, alternating; pass n may overwrite set n & 1 because every member
+    // has collected pass n - 2 before it asks for the step that pass n serves
+    float * d_out[2] = { nullptr, nullptr }, * h_out[2] = { nullptr, nullptr };       // [8][n_vocab] logits
+    unsigned * d_stat[2] = { nullptr, nullptr }, * h_stat[2] = { nullptr, nullptr };  // {status, sequence echo}, then the tokens the rows decoded [8]
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_k[2] = { nullptr, nullptr }, ev_c[2] = { nullptr, nullptr };
+    long n_launched = 0, n_ahead = 0, n_picks = 0;       // passes launched; run-ahead rows, rows whose token the device picked
+    wa_bpass passes[4];
+    bool slot_held = false;                         // this group holds the device's one-launch slot (while passes are in flight / members run ahead)
+    bool async_ok = true;
     // the pass for B rows as a hipGraph (122 launches for ggml-small): captured on first use, replayed while T and the cell count stay
     hipGraphExec_t graph[WA_MAX_DECODERS + 1] = {};
     int graph_T[WA_MAX_DECODERS + 1] = {}; uint32_t graph_kv[WA_MAX_DECODERS + 1] = {};
@@ -474,6 +522,10 @@ struct wa_batcher {
 // allocates a whole whisper_state, and its hipMalloc / hipFree calls synchronise the device under the other chunks' encoders.  wa_batcher_create
 // takes a free one (or makes one), wa_batcher_destroy hands it back; whisper_free releases them (wa_batcher_free_all).
 static std::mutex & batcher_cache_mutex() { static std::mutex m; return m; }
+static void batcher_reset(wa_batcher & b, int n_members) {
+    b.n_members = n_members; b.n_steps = b.n_rows = b.n_one_launch = 0; b.t_pass_us = b.t_gap_us = b.t_last_end = 0; b.n_ahead = b.n_picks = 0;
+    for (auto & sl : b.slots) { sl.st = nullptr; sl.q.clear(); sl.ahead = false; }
+}
 wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
     if (ctx.model.n_loaded == 0 || n_members < 2) return nullptr;
     wa_batcher * b = nullptr;
@@ -481,12 +533,10 @@ wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
         std::lock_guard<std::mutex> lk(batcher_cache_mutex());
         if (!ctx.batcher_cache.empty()) { b = (wa_batcher *) ctx.batcher_cache.back(); ctx.batcher_cache.pop_back(); }
     }
-    if (b) {
-        b->n_members = n_members; b->waiting.clear(); b->n_steps = b->n_rows = b->n_one_launch = 0; b->t_pass_us = b->t_gap_us = b->t_last_end = 0;
-        return b;
-    }
+    if (b) { batcher_reset(*b, n_members); return b; }
     b = new wa_batcher();
-    b->ctx = &ctx; b->n_members = n_members;
+    b->ctx = &ctx;
+    batcher_reset(*b, n_members);
     b->bst = whisper_init_state(&ctx);
     if (!b->bst || !WA_HIP_OK(hipHostMalloc((void **) &b->h_rowp, WA_MAX_DECODERS * sizeof(wa_rowptr))) ||
         !WA_HIP_OK(hipMalloc((void **) &b->d_rowp, WA_MAX_DECODERS * sizeof(wa_rowptr)))) { wa_batcher_release(b); return nullptr; }
@@ -495,6 +545,19 @@ wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
 void wa_batcher_release(wa_batcher * b) {
     if (!b) return;
     for (auto & g : b->graph) if (g) (void) hipGraphExecDestroy(g);
+    for (int i = 0; i < 2; ++i) {
+        if (b->d_out[i]) (void) hipFree(b->d_out[i]);
+        if (b->h_out[i]) (void) hipHostFree(b->h_out[i]);
+        if (b->d_stat[i]) (void) hipFree(b->d_stat[i]);
+        if (b->h_stat[i]) (void) hipHostFree(b->h_stat[i]);
+        if (b->ev_k[i]) (void) hipEventDestroy(b->ev_k[i]);
+        if (b->ev_c[i]) (void) hipEventDestroy(b->ev_c[i]);
+    }
+    for (auto & sl : b->slots) {
+        for (int i = 0; i < 2; ++i) { if (sl.d_rec[i]) (void) hipFree(sl.d_rec[i]); if (sl.d_ps[i]) (void) hipFree(sl.d_ps[i]); }
+        if (sl.d_smask) (void) hipFree(sl.d_smask);
+    }
+    if (b->copy_stream) (void) hipStreamDestroy(b->copy_stream);
     if (b->bst) whisper_free_state(b->bst);
     if (b->h_rowp) (void) hipHostFree(b->h_rowp);
     if (b->d_rowp) (void) hipFree(b->d_rowp);
@@ -512,117 +575,307 @@ void wa_batcher_free_all(whisper_context & ctx) {
 }
 void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows, long * one_launch) { if (b) { *steps = b->n_steps; *rows = b->n_rows; if (one_launch) *one_launch = b->n_one_launch; } }
 
-// all requests of `b->waiting` in one pass; called with b->m held by the thread that completed the set
-static void batcher_run(wa_batcher & b) {
+// the request of a member that the next pass serves: its oldest one that no pass serves yet (null: none)
+static wa_breq * batcher_next(wa_bslot & sl) {
+    for (auto & r : sl.q) if (r.pass == -1 && r.result == 0) return &r;
+    return nullptr;
+}
+static wa_bslot * batcher_slot(wa_batcher & b, whisper_state & st, bool make) {
+    for (auto & sl : b.slots) if (sl.st == &st) return &sl;
+    if (make) for (auto & sl : b.slots) if (!sl.st) { sl.st = &st; sl.q.clear(); sl.ahead = false; return &sl; }
+    return nullptr;
+}
+// buffers of the asynchronous passes, on first use
+static bool batcher_async_prepare(wa_batcher & b) {
+    if (b.d_out[0]) return true;
+    if (!b.async_ok) return false;
+    const size_t n_vocab = (size_t) b.ctx->model.hp.n_vocab;
+    bool ok = WA_HIP_OK(hipStreamCreateWithFlags(&b.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2 && ok; ++i) {
+        ok = WA_HIP_OK(hipMalloc((void **) &b.d_out[i], WA_MAX_DECODERS * n_vocab * sizeof(float))) && WA_HIP_OK(hipHostMalloc((void **) &b.h_out[i], WA_MAX_DECODERS * n_vocab * sizeof(float))) &&
+             WA_HIP_OK(hipMalloc((void **) &b.d_stat[i], 128)) && WA_HIP_OK(hipMemset(b.d_stat[i], 0, 128)) && WA_HIP_OK(hipHostMalloc((void **) &b.h_stat[i], 128)) &&
+             WA_HIP_OK(hipEventCreateWithFlags(&b.ev_k[i], hipEventDisableTiming)) && WA_HIP_OK(hipEventCreateWithFlags(&b.ev_c[i], hipEventDisableTiming));
+    }
+    if (!ok) b.async_ok = false;
+    return ok;
+}
+static void batcher_release_device(wa_batcher & b) {       // (b.m held) give the device's one-launch slot back once nothing of this group is in flight
+    if (!b.slot_held) return;
+    for (const auto & sl : b.slots) if (sl.st && (sl.ahead || !sl.q.empty())) return;
+    b.slot_held = false;
+    mega_slot(b.ctx->device).unlock();
+}
+
+// The requests of a group as ONE launch (wa_rows.hip), asynchronously: launch, copy the rows out behind it, record an event - no host wait here.
+// (b.m held)  false: not launched (the caller falls back)
+static bool batcher_launch_async(wa_batcher & b, wa_bslot ** run, int B, int T, uint32_t kv_size) {
     whisper_context & ctx = *b.ctx;
     whisper_state & bs = *b.bst;
-    const auto & hp = ctx.model.hp;
-    const int n_vocab = hp.n_vocab;
-    std::vector<wa_batcher::req *> reqs;
-    reqs.swap(b.waiting);
-    // members must agree on what the kernels take as launch-uniform: cells per layer and the audio context
-    const whisper_state & s0 = *reqs[0]->st;
-    const int T = s0.enc_n_ctx > 0 ? s0.enc_n_ctx : hp.n_audio_ctx;
-    std::vector<wa_batcher::req *> run;
-    for (auto * r : reqs) {
-        const whisper_state & s = *r->st;
-        const int Ts = s.enc_n_ctx > 0 ? s.enc_n_ctx : hp.n_audio_ctx;
-        if ((int) run.size() < WA_MAX_DECODERS && s.kv_self.size == s0.kv_self.size && Ts == T && s.cross_tpad == bs.cross_tpad) run.push_back(r);
-        else r->result = -1;                        // decoded by its own thread the ordinary way
+    const auto & m = ctx.model; const auto & hp = m.hp;
+    if (!bs.rows_enabled || bs.rows_pause > 0 || !batcher_async_prepare(b) || T < 1 || (T >> 5) > 47 || T > bs.cross_tpad) return false;
+    const int n_wg = std::min(m.n_cu, 256), quant = m.wtype != 1 ? 1 : 0;
+    wa_rows_args a;
+    memset(&a, 0, sizeof(a));
+    if (wa_rows_lds_bytes(hp.n_text_state, B, n_wg, quant, &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, bs)) return false;
+    for (int i = 0; i < B; ++i) { const wa_breq & r = *batcher_next(*run[i]); if (r.n_kv < 1 || r.n_kv > WA_ROWS_MAXKV || r.kv_head < 0 || r.kv_head >= r.n_kv) return false; }
+    const int par = (int) (b.n_launched & 1);
+    a.layers = (const wa_mega_layer *) m.d_mega_layers;
+    a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
+    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu; a.quant = quant;
+    if (quant) { a.te = (const wa_f16 *) m.te_q.qs; a.te_d = m.te_q.qd; }
+    a.kv_layer_stride = (unsigned long long) kv_size * hp.n_text_state;
+    a.cross_layer_stride = (unsigned long long) hp.n_text_head * bs.cross_tpad * 64; a.cross_tpad = bs.cross_tpad; a.T = T;
+    a.granules = bs.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = bs.d_rows_cgr;
+    a.logits = b.d_out[par]; a.status = b.d_stat[par]; a.tok_out = (int *) (b.d_stat[par] + 4); a.row_status = b.d_stat[par] + 12;
+    a.kq_scale = pow(float(64), -0.25); a.B = B; a.n_out = B;
+    a.token_beg = ctx.vocab.token_beg; a.token_eot = ctx.vocab.token_eot;
+    for (int i = 0; i < B; ++i) {
+        wa_bslot & sl = *run[i];
+        wa_breq & r = *batcher_next(sl);
+        whisper_state & ms = *sl.st;
+        wa_rows_row & rr = a.rows[i];
+        rr.kv_k = ms.kv_self.k; rr.kv_v = ms.kv_self.v; rr.cross_k = ms.d_cross_k; rr.cross_v = ms.d_cross_v; rr.mask = nullptr;
+        rr.n_kv = r.n_kv; rr.kv_head = r.kv_head; rr.token = r.token < 0 ? 0 : r.token; rr.pos = r.pos;
+        a.out_row[i] = i;
+        if (r.ahead) {
+            b.n_ahead += 1; if (r.token < 0) b.n_picks += 1;
+            const int p = r.k & 1;
+            rr.spec = r.token < 0 ? 1 : 0;
+            rr.rec_in = sl.d_rec[p ^ 1]; rr.rec_out = sl.d_rec[p]; rr.ps_in = sl.d_ps[p ^ 1]; rr.ps_out = sl.d_ps[p]; rr.smask = sl.d_smask;
+            rr.s_last = r.after.last; rr.s_penult = r.after.penult; rr.s_seek_delta = r.after.seek_delta; rr.s_has_ts = r.after.has_ts;
+        }
     }
-    const int B = (int) run.size();
+    bs.mega_seq += 1; if (bs.mega_seq == 0) bs.mega_seq = 1;
+    a.seq = bs.mega_seq;
+    if (!b.slot_held) { mega_slot(ctx.device).lock(); b.slot_held = true; }
+    hipStream_t s = bs.stream;
+    (void) hipMemsetAsync(b.d_stat[par] + 12, 0, WA_ROWS_MAX * sizeof(unsigned), s);
+    if (!wa_launch_decode_rows(s, a, n_wg)) { bs.rows_enabled = false; batcher_release_device(b); return false; }
+    (void) hipEventRecord(b.ev_k[par], s);
+    (void) hipStreamWaitEvent(b.copy_stream, b.ev_k[par], 0);
+    (void) hipMemcpyAsync(b.h_out[par], b.d_out[par], (size_t) B * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, b.copy_stream);
+    (void) hipMemcpyAsync(b.h_stat[par], b.d_stat[par], 128, hipMemcpyDeviceToHost, b.copy_stream);
+    (void) hipEventRecord(b.ev_c[par], b.copy_stream);
+    wa_bpass & ps = b.passes[b.n_launched & 3];
+    ps = wa_bpass(); ps.seq = a.seq; ps.B = B; ps.parity = par; ps.launched = true;
+    for (int i = 0; i < B; ++i) { wa_breq & r = *batcher_next(*run[i]); r.pass = b.n_launched; r.row = i; r.result = 1; }
+    b.n_launched += 1; b.n_steps += 1; b.n_rows += B; b.n_one_launch += 1;
+    return true;
+}
+
+// The same requests through the launch sequence, synchronously (no one-launch form: odd shapes, a paused form, WHISPER_AMD_NO_MEGA).  Run-ahead
+// requests cannot be served this way: their members are told to go on alone.  (b.m held)
+static void batcher_run_sync(wa_batcher & b, wa_bslot ** run, int B, int T, uint32_t kv_size) {
+    whisper_context & ctx = *b.ctx;
+    whisper_state & bs = *b.bst;
+    const int n_vocab = ctx.model.hp.n_vocab;
     const int64_t t_begin = wa_time_us();
     if (b.t_last_end) b.t_gap_us += t_begin - b.t_last_end;
-    bool ok = WA_HIP_OK(hipSetDevice(ctx.device));
-    // (tests: a pass whose launch failed must not hand out the stale contents of the staging buffer - every member then decodes alone)
-    static const bool test_fail = getenv("WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH") != nullptr;
-    if (test_fail) ok = false;
+    bool ok = ctx.model.wtype == 1;     // (the launch sequence of a quantised model has no per-row K / V form: the members decode alone)
+    for (int i = 0; i < B; ++i) if (batcher_next(*run[i])->ahead) ok = false;
     if (ok) {
         hipStream_t s = bs.stream;
         int32_t * h_tok = bs.h_stage_i32, * h_pos = h_tok + bs.dec_mpad, * h_rows = h_pos + bs.dec_mpad;
-        int n_kv_max = 1;
         for (int i = 0; i < B; ++i) {
-            whisper_state & ms = *run[i]->st;
-            h_tok[i] = run[i]->token; h_pos[i] = run[i]->pos; h_rows[i] = i;
-            b.h_rowp[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, run[i]->n_kv, run[i]->kv_head };
-            n_kv_max = std::max(n_kv_max, run[i]->n_kv);
+            whisper_state & ms = *run[i]->st; const wa_breq & r = *batcher_next(*run[i]);
+            h_tok[i] = r.token; h_pos[i] = r.pos; h_rows[i] = i;
+            b.h_rowp[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, r.n_kv, r.kv_head };
         }
         bs.enc_n_ctx = T;
-        // the pass as ONE launch (wa_rows.hip); the launch sequence below stays as the fallback
-        bool served = false;
-        if (bs.rows_enabled) {
-            wa_rows_row rr[WA_MAX_DECODERS];
-            for (int i = 0; i < B; ++i) {
-                whisper_state & ms = *run[i]->st;
-                rr[i] = { ms.kv_self.k, ms.kv_self.v, ms.d_cross_k, ms.d_cross_v, nullptr, run[i]->n_kv, run[i]->kv_head, run[i]->token, run[i]->pos };
-            }
-            served = rows_step(ctx, bs, B, rr, B, nullptr, T, bs.cross_tpad, s0.kv_self.size, true) == 1;
-            if (served) b.n_one_launch += 1;
-        }
-        if (!served && ctx.model.wtype != 1) ok = false;       // (the launch sequence of a quantised model has no per-row K / V form: the members decode alone)
-        else if (!served) {
         (void) hipMemcpyAsync(bs.d_tok, h_tok, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(bs.d_pos, h_pos, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(bs.d_rows, h_rows, B * sizeof(int32_t), hipMemcpyHostToDevice, s);
         (void) hipMemcpyAsync(b.d_rowp, b.h_rowp, B * sizeof(wa_rowptr), hipMemcpyHostToDevice, s);
         // (every row's own n_kv comes from its wa_rowptr; the launch-uniform n_kv only picks the kernel variant: <= 512 cells, one block per pair)
-        (void) n_kv_max;
         static const bool no_graph = getenv("WHISPER_AMD_NO_GRAPH") != nullptr;
-        if (b.graphs_ok && !no_graph && (!b.graph[B] || b.graph_T[B] != T || b.graph_kv[B] != s0.kv_self.size)) {
+        if (b.graphs_ok && !no_graph && (!b.graph[B] || b.graph_T[B] != T || b.graph_kv[B] != kv_size)) {
             if (b.graph[B]) { (void) hipGraphExecDestroy(b.graph[B]); b.graph[B] = nullptr; }
             hipGraph_t g = nullptr;
             if (WA_HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
-                decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
+                decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, kv_size);
                 if (WA_HIP_OK(hipStreamEndCapture(s, &g)) && g) {
                     if (!WA_HIP_OK(hipGraphInstantiate(&b.graph[B], g, nullptr, nullptr, 0))) b.graph[B] = nullptr;
                     (void) hipGraphDestroy(g);
                 }
             }
-            if (b.graph[B]) { b.graph_T[B] = T; b.graph_kv[B] = s0.kv_self.size; } else b.graphs_ok = false;
+            if (b.graph[B]) { b.graph_T[B] = T; b.graph_kv[B] = kv_size; } else b.graphs_ok = false;
         }
         if (b.graph[B] && !no_graph) ok = WA_HIP_OK(hipGraphLaunch(b.graph[B], s)) && ok;
-        else decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, s0.kv_self.size);
+        else decode_launch(ctx, bs, B, 512, 0, nullptr, B, false, nullptr, b.d_rowp, kv_size);
         ok = hipGetLastError() == hipSuccess && ok;
         (void) hipMemcpyAsync(bs.h_logits_pinned, bs.d_logits, (size_t) B * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
         ok = WA_HIP_OK(hipStreamSynchronize(s)) && ok;
         if (!ok) b.graphs_ok = false;
-        }
     }
-    // every member copies ITS row out on its own thread (the staging buffer is not written again before all of them are back with their next
-    // requests): eight 200 KB copies one after the other cost the group 0.15 ms per pass
-    for (int i = 0; i < B; ++i) { run[i]->row = bs.h_logits_pinned + (size_t) i * n_vocab; run[i]->result = ok ? 1 : -1; }
+    // every member copies ITS row out on its own thread (the staging buffer is not written again before all of them are back with their next requests)
+    for (int i = 0; i < B; ++i) { wa_breq & r = *batcher_next(*run[i]); r.pass = -2; r.row = i; r.result = ok ? 1 : -1; }
     b.n_steps += 1; b.n_rows += B;
     b.t_last_end = wa_time_us();
     b.t_pass_us += b.t_last_end - t_begin;
-    static const bool trace = getenv("WHISPER_AMD_BATCH_TRACE") != nullptr;
-    if (trace && (b.n_steps % 100) == 0) fprintf(stderr, "[batcher] %ld passes: %.3f ms in a pass, %.3f ms between passes (mean)\n", b.n_steps, 1e-3 * b.t_pass_us / b.n_steps, 1e-3 * b.t_gap_us / b.n_steps);
 }
 
-// a member's single-token step: 1 = logits delivered into st.logits, 0 = not served (the caller decodes it itself)
-static int batcher_step(wa_batcher & b, whisper_state & st, int token, int pos, int n_kv, int kv_head) {
+// (b.m held) launch a pass once every member still decoding has a request in that no pass serves yet
+static void batcher_try_launch(wa_batcher & b) {
+    wa_bslot * run[WA_MAX_DECODERS];
+    int n = 0;
+    for (auto & sl : b.slots) if (sl.st && batcher_next(sl)) run[n++] = &sl;
+    if (n == 0 || n < b.n_members) return;
+    whisper_context & ctx = *b.ctx;
+    const auto & hp = ctx.model.hp;
+    // members must agree on what the kernels take as launch-uniform: cells per layer and the audio context
+    const whisper_state & s0 = *run[0]->st;
+    const int T = s0.enc_n_ctx > 0 ? s0.enc_n_ctx : hp.n_audio_ctx;
+    wa_bslot * ok_run[WA_MAX_DECODERS]; int B = 0;
+    for (int i = 0; i < n; ++i) {
+        const whisper_state & s = *run[i]->st;
+        const int Ts = s.enc_n_ctx > 0 ? s.enc_n_ctx : hp.n_audio_ctx;
+        if (s.kv_self.size == s0.kv_self.size && Ts == T && s.cross_tpad == b.bst->cross_tpad) ok_run[B++] = run[i];
+        else batcher_next(*run[i])->result = -1;           // decoded by its own thread the ordinary way
+    }
+    // (tests: a pass whose launch failed must not hand out the stale contents of the staging buffer - every member then decodes alone)
+    static const bool test_fail = getenv("WHISPER_AMD_TEST_FAIL_BATCH_LAUNCH") != nullptr;
+    if (test_fail || !WA_HIP_OK(hipSetDevice(ctx.device))) { for (int i = 0; i < B; ++i) batcher_next(*ok_run[i])->result = -1; b.cv.notify_all(); return; }
+    if (B > 0 && !batcher_launch_async(b, ok_run, B, T, s0.kv_self.size)) {
+        bool any_ahead = false;
+        for (int i = 0; i < B; ++i) any_ahead = any_ahead || batcher_next(*ok_run[i])->ahead;
+        if (any_ahead) { for (int i = 0; i < B; ++i) for (auto & r : ok_run[i]->q) if (r.pass == -1 && r.result == 0) r.result = -1; }      // (no one-launch form: every member on its own from here)
+        else batcher_run_sync(b, ok_run, B, T, s0.kv_self.size);
+    }
+    static const bool trace = getenv("WHISPER_AMD_BATCH_TRACE") != nullptr;
+    if (trace && (b.n_steps % 100) == 0) fprintf(stderr, "[batcher] %ld passes (%ld as one launch; %ld run-ahead rows, %ld picked by the device): %.3f ms in a synchronous pass, %.3f ms between them (mean)\n", b.n_steps, b.n_one_launch, b.n_ahead, b.n_picks,
+                                                 1e-3 * b.t_pass_us / std::max(1L, b.n_steps), 1e-3 * b.t_gap_us / std::max(1L, b.n_steps));
+    b.cv.notify_all();
+}
+
+// Collect the request `k` of a member: wait until a pass serves it and has finished, copy the member's logits row into st.logits.
+// 0 = done, 1 = the pass wants to be redone by the launch sequence (an uncertifiable soft-max sum), -1 = not served / the form gave up.
+static int batcher_collect(wa_batcher & b, wa_bslot & sl, int * token_used) {
     std::unique_lock<std::mutex> lk(b.m);
-    if (b.n_members < 2) return 0;                  // the last chunk still decoding: nothing to share a pass with
-    wa_batcher::req r = { &st, token, pos, n_kv, kv_head, 0, nullptr };
-    b.waiting.push_back(&r);
-    if ((int) b.waiting.size() >= b.n_members) { batcher_run(b); b.cv.notify_all(); }
-    else b.cv.wait(lk, [&] { return r.result != 0; });
-    lk.unlock();
-    if (r.result != 1) return 0;
+    if (sl.q.empty()) return -1;
+    b.cv.wait(lk, [&] { return sl.q.front().result != 0; });
+    wa_breq r = sl.q.front();
     const size_t n_vocab = (size_t) b.ctx->model.hp.n_vocab;
+    if (r.result != 1) { sl.q.pop_front(); batcher_release_device(b); return -1; }
+    whisper_state & st = *sl.st;
+    if (r.pass == -2) {             // a synchronous pass: the row is in the private state's staging buffer
+        const float * row = b.bst->h_logits_pinned + (size_t) r.row * n_vocab;
+        sl.q.pop_front();
+        lk.unlock();
+        st.logits.resize(n_vocab);
+        memcpy(st.logits.data(), row, n_vocab * sizeof(float));
+        return 0;
+    }
+    wa_bpass & ps = b.passes[r.pass & 3];
+    const int par = ps.parity;
+    lk.unlock();
+    const bool synced = WA_HIP_OK(hipEventSynchronize(b.ev_c[par]));
+    lk.lock();
+    if (!ps.done) {                 // the first member back reads the pass's status word and the echo of its sequence number
+        ps.done = true;
+        ps.status = synced ? b.h_stat[par][0] : 9998u;
+        ps.ok = synced && ps.status == 0 && b.h_stat[par][1] == ps.seq;
+        if (!ps.ok) {
+            whisper_state & bs = *b.bst;
+            bs.n_rows_fallback += 1;
+            static const bool trace_f = getenv("WHISPER_AMD_BATCH_TRACE") != nullptr;
+            if (trace_f) { const int * tk = (const int *) (b.h_stat[par] + 4); fprintf(stderr, "[batcher] pass %ld failed: status %u echo %u seq %u B %d tokens %d %d %d %d %d %d %d %d  logits[0][0..3] %g %g %g %g\n", r.pass, ps.status, b.h_stat[par][1], ps.seq, ps.B,
+                                    tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], b.h_out[par][0], b.h_out[par][1], b.h_out[par][2], b.h_out[par][3]); }
+            (void) hipMemsetAsync(b.d_stat[par], 0, sizeof(unsigned), bs.stream);
+            if (ps.status != WA_MEGA_REDO) one_launch_timeout(bs.rows_pause, bs.rows_timeouts, bs.rows_enabled, "several-rows one-launch step (lock-step group)", ps.status);
+        } else b.bst->n_rows_steps += 1;
+    }
+    const bool ok = ps.ok && b.h_stat[par][12 + r.row] == 0;
+    const unsigned status = ps.ok ? b.h_stat[par][12 + r.row] : ps.status;      // (WA_MEGA_REDO for THIS row: its member has the step redone, the others go on)
+    const float * row = b.h_out[par] + (size_t) r.row * n_vocab;
+    if (token_used) *token_used = ((const int *) (b.h_stat[par] + 4))[r.row];
+    sl.q.pop_front();
+    batcher_release_device(b);
+    lk.unlock();
+    if (!ok) return status == WA_MEGA_REDO ? 1 : -1;
     st.logits.resize(n_vocab);
-    memcpy(st.logits.data(), r.row, n_vocab * sizeof(float));
-    return 1;
+    memcpy(st.logits.data(), row, n_vocab * sizeof(float));
+    return 0;
+}
+
+// a member's plain single-token step: 1 = logits delivered into st.logits, 0 = not served (the caller decodes it itself)
+static int batcher_step(wa_batcher & b, whisper_state & st, int token, int pos, int n_kv, int kv_head) {
+    wa_bslot * sl;
+    {
+        std::unique_lock<std::mutex> lk(b.m);
+        if (b.n_members < 2) return 0;                  // the last chunk still decoding: nothing to share a pass with
+        sl = batcher_slot(b, st, true);
+        if (!sl || !sl->q.empty()) return 0;
+        wa_breq r; r.token = token; r.pos = pos; r.n_kv = n_kv; r.kv_head = kv_head;
+        sl->q.push_back(r);
+        batcher_try_launch(b);
+    }
+    return batcher_collect(b, *sl, nullptr) == 0 ? 1 : 0;
 }
 // a member is done (or failed): the others no longer wait for it
 void wa_batcher_leave(wa_batcher * b) {
     if (!b) return;
     std::unique_lock<std::mutex> lk(b->m);
     b->n_members -= 1;
-    if (!b->waiting.empty() && (int) b->waiting.size() >= b->n_members) {
-        if (b->n_members >= 2 || (int) b->waiting.size() >= 2) batcher_run(*b);
-        else { for (auto * r : b->waiting) r->result = -1; b->waiting.clear(); }
-        b->cv.notify_all();
+    if (b->n_members < 2) {         // nobody to share a pass with: whoever still waits decodes alone
+        bool any = false;
+        for (auto & sl : b->slots) for (auto & r : sl.q) if (r.pass == -1 && r.result == 0) { r.result = -1; any = true; }
+        if (any) b->cv.notify_all();
+    } else batcher_try_launch(*b);
+}
+
+// ---- run-ahead windows of lock-step members (the wa_spec_* protocol of wa_full.cpp, served by the group's passes) ----
+static bool bspec_begin(wa_batcher & b, whisper_state & st, const std::vector<uint32_t> & bits) {
+    whisper_context & ctx = *b.ctx;
+    static const bool trace_b = getenv("WHISPER_AMD_BATCH_TRACE") != nullptr;
+    if (trace_b) fprintf(stderr, "[batcher] run-ahead window asked for: members %d rows_enabled %d pause %d\n", b.n_members, (int) b.bst->rows_enabled, b.bst->rows_pause);
+    const size_t n_mask = (size_t) ctx.model.hp.n_vocab / 32 + 2;
+    std::unique_lock<std::mutex> lk(b.m);
+    if (b.n_members < 2 || !b.bst->rows_enabled || b.bst->rows_pause > 0 || bits.size() > n_mask) return false;
+    static const bool off = getenv("WHISPER_AMD_NO_RUN_AHEAD") != nullptr;
+    if (off || !batcher_async_prepare(b)) return false;
+    wa_bslot * sl = batcher_slot(b, st, true);
+    if (!sl || !sl->q.empty()) return false;
+    if (!sl->d_smask) {
+        bool ok = WA_HIP_OK(hipMalloc((void **) &sl->d_smask, n_mask * 4));
+        for (int i = 0; i < 2 && ok; ++i) ok = WA_HIP_OK(hipMalloc((void **) &sl->d_rec[i], 512 * 8 * 4)) && WA_HIP_OK(hipMemset(sl->d_rec[i], 0, 512 * 8 * 4)) &&
+                                               WA_HIP_OK(hipMalloc((void **) &sl->d_ps[i], 32)) && WA_HIP_OK(hipMemset(sl->d_ps[i], 0, 32));
+        if (!ok) return false;
     }
+    std::vector<uint32_t> up(n_mask, 0u);
+    std::copy(bits.begin(), bits.end(), up.begin());
+    if (const char * e = getenv("WHISPER_AMD_OVERLAP_SABOTAGE")) if (e[0] == '1') for (size_t i = 0; i < up.size(); ++i) up[i] |= 0x49249249u << (i % 3);      // (tests: wrong predictions on purpose)
+    if (!WA_HIP_OK(hipMemcpy(sl->d_smask, up.data(), n_mask * 4, hipMemcpyHostToDevice))) return false;
+    sl->ahead = true;
+    return true;
+}
+static bool bspec_launch(wa_batcher & b, whisper_state & st, int k, int pos, int token, const wa_spec_state & after) {
+    std::unique_lock<std::mutex> lk(b.m);
+    wa_bslot * sl = batcher_slot(b, st, false);
+    if (!sl || !sl->ahead || sl->q.size() >= 2 || b.n_members < 2) return false;
+    wa_breq r; r.k = k; r.token = token; r.pos = pos; r.n_kv = pos + 1; r.kv_head = pos; r.ahead = true; r.after = after;      // greedy steady state: cell == position
+    sl->q.push_back(r);
+    batcher_try_launch(b);
+    return true;
+}
+static int bspec_wait(wa_batcher & b, whisper_state & st, int * token_used) {
+    wa_bslot * sl;
+    { std::unique_lock<std::mutex> lk(b.m); sl = batcher_slot(b, st, false); }
+    return sl ? batcher_collect(b, *sl, token_used) : -1;
+}
+static void bspec_drain(wa_batcher & b, whisper_state & st) {          // everything of this member that is in flight: waited for and dropped
+    wa_bslot * sl;
+    { std::unique_lock<std::mutex> lk(b.m); sl = batcher_slot(b, st, false); if (!sl) return;
+      for (auto & r : sl->q) if (r.pass == -1 && r.result == 0) r.result = -1; }
+    for (;;) {
+        { std::unique_lock<std::mutex> lk(b.m); if (sl->q.empty()) break; }
+        (void) batcher_collect(b, *sl, nullptr);
+    }
+}
+static void bspec_end(wa_batcher & b, whisper_state & st) {
+    bspec_drain(b, st);
+    std::unique_lock<std::mutex> lk(b.m);
+    if (wa_bslot * sl = batcher_slot(b, st, false)) sl->ahead = false;
+    batcher_release_device(b);
 }
 
 bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch, bool save_aheads, ggml_abort_callback abort_cb,
@@ -678,7 +931,8 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     for (size_t i = 0; i < (size_t) n_tokens * n_kv && !need_mask; ++i) need_mask = h_mask[i] != 0;
     const bool steady = n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads;
     bool done = false, from_batcher = false;
-    if (steady && st.batcher) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    const bool solo = st.solo_step; st.solo_step = false;
+    if (steady && st.batcher && !solo) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done && steady && st.mega_enabled && st.mega_pause > 0) st.mega_pause -= 1;      // (paused after a time-out: this pass takes the launch sequence)
     else if (!done && steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && n_kv <= WA_ROWS_MAXKV) {
@@ -865,7 +1119,7 @@ static bool rows_probe_args(whisper_context & ctx, whisper_state & own, whisper_
     a.kv_layer_stride = (unsigned long long) own.kv_self.size * hp.n_text_state;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * own.cross_tpad * 64; a.cross_tpad = own.cross_tpad; a.T = T;
     a.granules = own.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = own.d_rows_cgr;
-    a.logits = own.d_logits; a.status = own.d_rows_status; a.kq_scale = pow(float(64), -0.25); a.B = B;
+    a.logits = own.d_logits; a.status = own.d_rows_status; a.row_status = own.d_rows_status + 4; a.kq_scale = pow(float(64), -0.25); a.B = B;
     a.n_out = B; for (int i = 0; i < B; ++i) a.out_row[i] = i;
     for (int i = 0; i < B; ++i) {
         whisper_state & ms = sts && sts[i] ? *sts[i] : own;

@@ -53,7 +53,7 @@ bool wa_rows_prepare(whisper_context & ctx, whisper_state & st) {
     const int dt = hp.n_text_state, Ht = hp.n_text_head;
     const size_t row_gr = (size_t) 2 * dt;
     if (!dev_alloc(st.d_rows_gr, (size_t) hp.n_text_layer * WA_MEGA_EDGES * WA_ROWS_MAX * row_gr) ||
-        !dev_alloc(st.d_rows_cgr, (size_t) hp.n_text_layer * WA_ROWS_MAX * Ht * WA_ROWS_CGR) || !dev_alloc(st.d_rows_status, 16)) {
+        !dev_alloc(st.d_rows_cgr, (size_t) hp.n_text_layer * WA_ROWS_MAX * Ht * WA_ROWS_CGR) || !dev_alloc(st.d_rows_status, 32)) {
         dev_free(st.d_rows_gr); dev_free(st.d_rows_cgr); dev_free(st.d_rows_status);
         st.rows_enabled = false;
         return false;

@@ -711,7 +711,7 @@ int runner::run(const float * samples, int n_samples) {
                 const auto & kvc = st->kv_self;
                 const bool seq_cells = wa_kv_cell_max(kvc) == P && P < (int) kvc.size && kvc.cells[P].pos < 0;
                 if (!(e && e[0] == '1') && p.strategy == WHISPER_SAMPLING_GREEDY && n_dec == 1 && t_cur < 1e-6f && !p.logits_filter_callback &&
-                    st->mega_enabled && st->mega_pause == 0 && !st->batcher && ctx->model.n_loaded > 0 && seq_cells)      // (a lock-step member: its steps go through the group's passes)
+                    ((st->mega_enabled && st->mega_pause == 0) || st->batcher) && ctx->model.n_loaded > 0 && seq_cells)      // (a lock-step member: the window runs on its group's passes)
                     ov.on = wa_spec_begin(*ctx, *st, suppress_bits());
             }
 
@@ -842,7 +842,15 @@ int runner::run(const float * samples, int n_samples) {
                             st->kv_self.n = std::min(st->kv_self.size, (uint32_t) std::max(1, wa_kv_cell_max(st->kv_self)));
                             if (p.abort_callback && p.abort_callback(p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -9; }
                             have_logits = true;
+                        } else if (rc == 1 && st->batcher) {
+                            // this member's row of the pass wants the launch sequence (an uncertifiable soft-max sum): the step is decoded below the plain
+                            // way, the window goes on behind it - the next iteration asks for step i + 1 with its token, then runs ahead again
+                            wa_spec_drain(*ctx, *st);
+                            ov_launched = i + 1;
+                            st->solo_step = true;       // (the same inputs would send the group's pass back again)
                         } else {        // the one-launch step is not available for this token (or any more): finish the window the plain way
+                            static const bool trace_w = getenv("WHISPER_AMD_BATCH_TRACE") != nullptr;
+                            if (trace_w) fprintf(stderr, "[full] overlap window ends at step %d: ok %d rc %d used %d launched %d\n", i, (int) ok, rc, used, ov_launched);
                             wa_spec_drain(*ctx, *st);
                             wa_spec_end(*ctx, *st);
                             ov.on = false;

@@ -272,6 +272,7 @@ struct whisper_state {
     bool rows_enabled = false;
     long n_rows_steps = 0, n_rows_fallback = 0;      // passes served by the one-launch form / sent to the launch sequence after a status
     struct wa_batcher * batcher = nullptr;   // set while this state is a member of a whisper_amd_full_batch call (wa_decode.cpp)
+    bool solo_step = false;                  // the next plain step of a lock-step member is decoded by the member alone (its row of a pass asked to be redone by the launch sequence)
     bool spec_owner = false;                 // this state holds its device's one-launch slot (wa_spec_begin .. wa_spec_end)
     hipEvent_t ev_k[2] = { nullptr, nullptr }, ev_c[2] = { nullptr, nullptr };
     int n_spec_ok = 0, n_spec_miss = 0;

@@ -48,7 +48,10 @@ struct wa_rows_args {
     unsigned long long * cross_gr;                      // [layer][B][head][WA_ROWS_CGR]
     float * logits;                                     // [B][n_vocab]
     unsigned * status;                                  // [0] 0 = ok, else the code of the hand-off that timed out; [1] = seq once the launch has run
+    unsigned * row_status;                              // [B] (cleared by the caller) WA_MEGA_REDO: a soft-max sum of this row could not be certified order-independent -
+                                                        // the row's logits may be an ulp off, the row is to be redone by the launch sequence; the other rows stand
     float * dbg;
+    int * tok_out;                                      // [B] the token every row decoded (given, or picked from its records), null: not wanted
     float kq_scale; unsigned seq;
     int B, slot_bytes;
     int token_beg, token_eot;                           // (records) first timestamp token, end-of-text token

@@ -789,7 +789,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         }
         const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
         const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
-        if (ilo != ihi && lane == 0 && !c.dead) __hip_atomic_store(c.status, (unsigned) WA_MEGA_REDO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ilo != ihi && lane == 0) ((GAS unsigned *) A->row_status)[b] = (unsigned) WA_MEGA_REDO;      // (this row only: the pass goes on)
         if (lane == 0) bc[1] = ilo;
     }
     mb_barrier();
@@ -1082,6 +1082,7 @@ __device__ __forceinline__ void mb_pick(mb_kargs A, int b, int lane, int * pk, i
             GAS int * po = (GAS int *) A->rows[b].ps_out;
             po[0] = last; po[1] = penult; po[2] = seek_delta; po[3] = has_ts; po[4] = token;
         }
+        if (blockIdx.x == 0 && A->tok_out) ((GAS int *) A->tok_out)[b] = token;
     }
 }
 // candidate records of logits row m (token row br) from this workgroup's share of the logits, kept in LDS by mb_logits (lg [BT][256]); all threads
