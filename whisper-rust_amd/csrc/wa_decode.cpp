@@ -501,7 +501,7 @@ struct wa_batcher {
     int n_members = 0;                              // threads that may still submit
     wa_bslot slots[WA_MAX_DECODERS];
     long n_steps = 0, n_rows = 0, n_one_launch = 0;       // passes, the token rows they served, passes that were ONE launch (wa_rows.hip)
-    int64_t t_pass_us = 0, t_gap_us = 0, t_last_end = 0;   // (WHISPER_AMD_BATCH_TRACE) time inside the synchronous passes / between them
+    int64_t t_pass_us = 0, t_gap_us = 0, t_last_end = 0, t_created = 0, t_first = 0;   // (WHISPER_AMD_BATCH_TRACE) time inside the synchronous passes / between them
     // asynchronous passes (the one-launch form): two sets of output buffers, alternating; pass n may overwrite set n & 1 because every member
     // has collected pass n - 2 before it asks for the step that pass n serves
     float * d_out[2] = { nullptr, nullptr }, * h_out[2] = { nullptr, nullptr };       // [8][n_vocab] logits
@@ -523,7 +523,7 @@ struct wa_batcher {
 // takes a free one (or makes one), wa_batcher_destroy hands it back; whisper_free releases them (wa_batcher_free_all).
 static std::mutex & batcher_cache_mutex() { static std::mutex m; return m; }
 static void batcher_reset(wa_batcher & b, int n_members) {
-    b.n_members = n_members; b.n_steps = b.n_rows = b.n_one_launch = 0; b.t_pass_us = b.t_gap_us = b.t_last_end = 0; b.n_ahead = b.n_picks = 0;
+    b.n_members = n_members; b.n_steps = b.n_rows = b.n_one_launch = 0; b.t_pass_us = b.t_gap_us = b.t_last_end = 0; b.t_created = wa_time_us(); b.t_first = 0; b.n_ahead = b.n_picks = 0;
     for (auto & sl : b.slots) { sl.st = nullptr; sl.q.clear(); sl.ahead = false; }
 }
 wa_batcher * wa_batcher_create(whisper_context & ctx, int n_members) {
@@ -626,7 +626,10 @@ static bool batcher_launch_async(wa_batcher & b, wa_bslot ** run, int B, int T, 
     a.kv_layer_stride = (unsigned long long) kv_size * hp.n_text_state;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * bs.cross_tpad * 64; a.cross_tpad = bs.cross_tpad; a.T = T;
     a.granules = bs.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = bs.d_rows_cgr;
-    a.logits = b.d_out[par]; a.status = b.d_stat[par]; a.tok_out = (int *) (b.d_stat[par] + 4); a.row_status = b.d_stat[par] + 12;
+    static const bool host_out_env = getenv("WHISPER_AMD_ROWS_HOST_OUT") != nullptr && atoi(getenv("WHISPER_AMD_ROWS_HOST_OUT")) != 0;
+    float * h_dev = nullptr;
+    const bool host_out = host_out_env && hipHostGetDevicePointer((void **) &h_dev, b.h_out[par], 0) == hipSuccess && h_dev;
+    a.logits = host_out ? h_dev : b.d_out[par]; a.status = b.d_stat[par]; a.tok_out = (int *) (b.d_stat[par] + 4); a.row_status = b.d_stat[par] + 12;
     a.kq_scale = pow(float(64), -0.25); a.B = B; a.n_out = B;
     a.token_beg = ctx.vocab.token_beg; a.token_eot = ctx.vocab.token_eot;
     for (int i = 0; i < B; ++i) {
@@ -651,11 +654,12 @@ static bool batcher_launch_async(wa_batcher & b, wa_bslot ** run, int B, int T, 
     hipStream_t s = bs.stream;
     (void) hipMemsetAsync(b.d_stat[par] + 12, 0, WA_ROWS_MAX * sizeof(unsigned), s);
     if (!wa_launch_decode_rows(s, a, n_wg)) { bs.rows_enabled = false; batcher_release_device(b); return false; }
-    (void) hipEventRecord(b.ev_k[par], s);
-    (void) hipStreamWaitEvent(b.copy_stream, b.ev_k[par], 0);
-    (void) hipMemcpyAsync(b.h_out[par], b.d_out[par], (size_t) B * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, b.copy_stream);
-    (void) hipMemcpyAsync(b.h_stat[par], b.d_stat[par], 128, hipMemcpyDeviceToHost, b.copy_stream);
-    (void) hipEventRecord(b.ev_c[par], b.copy_stream);
+    // The rows go out on the SAME stream, in front of the next pass.  (On a stream of their own they were a copy kernel running beside the next
+    // pass's persistent workgroups, which starved it: 1.66 MB took 0.95 ms - the members got pass k's logits when pass k + 1 ended, and every
+    // second pass started 0.4 ms late.  WHISPER_AMD_ROWS_HOST_OUT=1: the kernel stores the logits into the pinned host rows itself.)
+    if (!host_out) (void) hipMemcpyAsync(b.h_out[par], b.d_out[par], (size_t) B * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
+    (void) hipMemcpyAsync(b.h_stat[par], b.d_stat[par], 128, hipMemcpyDeviceToHost, s);
+    (void) hipEventRecord(b.ev_c[par], s);
     wa_bpass & ps = b.passes[b.n_launched & 3];
     ps = wa_bpass(); ps.seq = a.seq; ps.B = B; ps.parity = par; ps.launched = true;
     for (int i = 0; i < B; ++i) { wa_breq & r = *batcher_next(*run[i]); r.pass = b.n_launched; r.row = i; r.result = 1; }
@@ -742,8 +746,9 @@ static void batcher_try_launch(wa_batcher & b) {
         else batcher_run_sync(b, ok_run, B, T, s0.kv_self.size);
     }
     static const bool trace = getenv("WHISPER_AMD_BATCH_TRACE") != nullptr;
-    if (trace && (b.n_steps % 100) == 0) fprintf(stderr, "[batcher] %ld passes (%ld as one launch; %ld run-ahead rows, %ld picked by the device): %.3f ms in a synchronous pass, %.3f ms between them (mean)\n", b.n_steps, b.n_one_launch, b.n_ahead, b.n_picks,
-                                                 1e-3 * b.t_pass_us / std::max(1L, b.n_steps), 1e-3 * b.t_gap_us / std::max(1L, b.n_steps));
+    if (trace && b.n_steps == 1) b.t_first = wa_time_us();
+    if (trace && (b.n_steps % 100) == 0) fprintf(stderr, "[batcher] %ld passes (%ld as one launch; %ld run-ahead rows, %ld picked by the device): %.3f ms in a synchronous pass, %.3f ms between them (mean); first pass %.1f ms after the group formed, now %.1f ms\n", b.n_steps, b.n_one_launch, b.n_ahead, b.n_picks,
+                                                 1e-3 * b.t_pass_us / std::max(1L, b.n_steps), 1e-3 * b.t_gap_us / std::max(1L, b.n_steps), 1e-3 * (b.t_first - b.t_created), 1e-3 * (wa_time_us() - b.t_created));
     b.cv.notify_all();
 }
 
@@ -932,10 +937,11 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     const bool steady = n_tokens == 1 && n_rows == 1 && !need_mask && !save_aheads;
     bool done = false, from_batcher = false;
     const bool solo = st.solo_step; st.solo_step = false;
+    const bool device_free = wa_encoders_in_flight(ctx.device).load(std::memory_order_relaxed) == 0;      // (wa_internal.h: no one-launch step beside encoder passes)
     if (steady && st.batcher && !solo) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done && steady && st.mega_enabled && st.mega_pause > 0) st.mega_pause -= 1;      // (paused after a time-out: this pass takes the launch sequence)
-    else if (!done && steady && st.mega_enabled) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
-    if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && n_kv <= WA_ROWS_MAXKV) {
+    else if (!done && steady && st.mega_enabled && device_free) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
+    if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && n_kv <= WA_ROWS_MAXKV && device_free) {
         // one token per live decoder (beam search, best_of, the bench's small batches): all rows in ONE launch (wa_rows.hip)
         if (need_mask) (void) hipMemcpyAsync(st.d_mask, h_mask, (size_t) n_tokens * n_kv, hipMemcpyHostToDevice, s);
         wa_rows_row rr[WA_MAX_DECODERS];

@@ -238,8 +238,14 @@ bool wa_mel_set(whisper_context & ctx, whisper_state & st, const float * data, i
 // -------------------------------------------------------------------------------------------------
 // encoder
 // -------------------------------------------------------------------------------------------------
+std::atomic<int> & wa_encoders_in_flight(int device) {
+    static std::atomic<int> n[64];
+    return n[device >= 0 && device < 64 ? device : 0];
+}
+
 bool wa_encode(whisper_context & ctx, whisper_state & st, int mel_offset, ggml_abort_callback abort_cb, void * abort_data) {
     const int64_t t0 = wa_time_us();
+    struct in_flight { std::atomic<int> & n; in_flight(std::atomic<int> & a) : n(a) { n.fetch_add(1); } ~in_flight() { n.fetch_sub(1); } } busy(wa_encoders_in_flight(ctx.device));
     const auto & m  = ctx.model;
     const auto & hp = m.hp;
     if (!WA_HIP_OK(hipSetDevice(ctx.device))) return false;

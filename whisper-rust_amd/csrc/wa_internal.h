@@ -18,6 +18,7 @@
 #include <random>
 #include <set>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #define WA_MAX_DECODERS 8          // ref: whisper.cpp:148 (WHISPER_MAX_DECODERS)
@@ -332,6 +333,10 @@ void wa_batcher_stats(const wa_batcher * b, long * steps, long * rows, long * on
 bool wa_state_alloc(whisper_context & ctx, whisper_state & st);
 void wa_state_release(whisper_state & st);
 bool wa_kv_self_realloc(whisper_context & ctx, whisper_state & st, int n_cells);
+// Encoder passes in flight on a device (wa_encode.cpp).  A one-launch decode step needs every CU's LDS to itself: beside several streams of
+// encoder launches its workgroups can wait many milliseconds for a free CU (seen: a hand-off time-out in a chunk's prompt pass while seven
+// other chunks of its group were still encoding).  Steps outside a window take the launch sequence while this is non-zero.
+std::atomic<int> & wa_encoders_in_flight(int device);
 bool wa_rows_prepare(whisper_context & ctx, whisper_state & st);      // buffers of the several-rows one-launch step (wa_encode.cpp); false: not available
 
 std::vector<int> wa_tokenize(const wa_vocab & vocab, const std::string & text);       // wa_api.cpp
