@@ -626,7 +626,9 @@ static bool batcher_launch_async(wa_batcher & b, wa_bslot ** run, int B, int T, 
     a.kv_layer_stride = (unsigned long long) kv_size * hp.n_text_state;
     a.cross_layer_stride = (unsigned long long) hp.n_text_head * bs.cross_tpad * 64; a.cross_tpad = bs.cross_tpad; a.T = T;
     a.granules = bs.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = bs.d_rows_cgr;
-    static const bool host_out_env = getenv("WHISPER_AMD_ROWS_HOST_OUT") != nullptr && atoi(getenv("WHISPER_AMD_ROWS_HOST_OUT")) != 0;
+    // the logits rows go straight into the pinned host rows (whole 256-byte stores, wa_rows.hip: mb_logits_out): kernel + 15 us instead of kernel - 30 us + a
+    // 63 us copy per pass (WHISPER_AMD_ROWS_HOST_OUT=0: through device memory and a copy)
+    static const bool host_out_env = getenv("WHISPER_AMD_ROWS_HOST_OUT") == nullptr || atoi(getenv("WHISPER_AMD_ROWS_HOST_OUT")) != 0;
     float * h_dev = nullptr;
     const bool host_out = host_out_env && hipHostGetDevicePointer((void **) &h_dev, b.h_out[par], 0) == hipSuccess && h_dev;
     a.logits = host_out ? h_dev : b.d_out[par]; a.status = b.d_stat[par]; a.tok_out = (int *) (b.d_stat[par] + 4); a.row_status = b.d_stat[par] + 12;
@@ -656,7 +658,8 @@ static bool batcher_launch_async(wa_batcher & b, wa_bslot ** run, int B, int T, 
     if (!wa_launch_decode_rows(s, a, n_wg)) { bs.rows_enabled = false; batcher_release_device(b); return false; }
     // The rows go out on the SAME stream, in front of the next pass.  (On a stream of their own they were a copy kernel running beside the next
     // pass's persistent workgroups, which starved it: 1.66 MB took 0.95 ms - the members got pass k's logits when pass k + 1 ended, and every
-    // second pass started 0.4 ms late.  WHISPER_AMD_ROWS_HOST_OUT=1: the kernel stores the logits into the pinned host rows itself.)
+    // second pass started 0.4 ms late; passes alternating between two streams, so that a copy could overlap the next kernel, gave the same starved copy
+    // kernel.  On the pass's stream the copy is a DMA of 63 us; by default there is none: host_out above.)
     if (!host_out) (void) hipMemcpyAsync(b.h_out[par], b.d_out[par], (size_t) B * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     (void) hipMemcpyAsync(b.h_stat[par], b.d_stat[par], 128, hipMemcpyDeviceToHost, s);
     (void) hipEventRecord(b.ev_c[par], s);

@@ -6,6 +6,7 @@
 // explicit phases); every rule cites the reference lines it reproduces.  All device work goes through
 // wa_encode / wa_decode.
 #include "wa_internal.h"
+#include "wa_expf8.h"
 
 #include <algorithm>
 #include <array>
@@ -57,6 +58,7 @@ inline float max_f32(const float * x, size_t n) {
 
 float logsumexp_ref_order(const float * logits, int n, size_t n_max = 0) {
     const float mx = max_f32(logits, n_max > (size_t) n ? n_max : (size_t) n);
+    if (wa_expf8_usable()) return logf(wa_sum_expf8(logits, n, mx)) + mx;      // the same sum, eight expf at a time (wa_expf8.h)
     float S = 0.0f;
     float thr = -INFINITY;                  // terms with (logits[i] - mx) < thr leave S unchanged
     auto add = [&](int i) {                 // index order is preserved: candidates of a block are visited in order
@@ -91,6 +93,7 @@ void compute_logprobs(const float * logits, int n, float * logprobs, size_t n_ma
     for (; i < n; ++i) logprobs[i] = logits[i] > -INFINITY ? logits[i] - lse : -INFINITY;
 }
 void compute_probs(const float * logits, int n, const float * logprobs, float * probs) {
+    if (wa_expf8_usable()) { wa_probs_expf8(logits, n, logprobs, probs); return; }
     for (int i = 0; i < n; ++i) probs[i] = logits[i] == -INFINITY ? 0.0f : expf(logprobs[i]);
 }
 
@@ -341,6 +344,9 @@ struct runner {
     std::vector<int> suppress_ids;      // tokens killed by suppress_regex / suppress_nst, resolved once per call
     int blank_id = -1;
     std::unique_ptr<wa_pool> pool;      // created with the first multi-decoder step
+    // (WHISPER_AMD_SAMPLE_TRACE) where decoder 0's host time goes: logit rules + log-soft-max, probabilities, top-k draws, beam bookkeeping, state machine
+    int64_t tr_rules = 0, tr_probs = 0, tr_topk = 0, tr_beam = 0, tr_state = 0, tr_steps = 0;
+    const bool tr_on = getenv("WHISPER_AMD_SAMPLE_TRACE") != nullptr;
     void par_for(int n, const std::function<void(int)> & f) {
         // one thread per decoder (up to 8): n_threads is sized for a CPU engine's matrix products, which this backend does not run
         if (n > 1 && !pool) pool.reset(new wa_pool(std::min(n, 8) - 1));
@@ -383,6 +389,7 @@ struct runner {
     // `full_probs`: the samplers that draw from the distribution need every probs[i]; the greedy arg-max needs only
     // the timestamp range and the candidates around the maximum (sample_token_best), so the 51865 expf calls are skipped.
     void process_logits(wa_decoder & dec, float temperature, bool full_probs) {
+        const int64_t tr0 = tr_on ? wa_time_us() : 0;
         const auto & cur = dec.sequence.tokens;
         const bool is_initial = cur.empty();
         const int n = n_vocab;
@@ -428,14 +435,17 @@ struct runner {
             {
                 const float mx = max_f32(logprobs + vocab.token_beg, n - vocab.token_beg);
                 float lse = 0.0f;
-                for (int i = vocab.token_beg; i < n; ++i) if (logprobs[i] > -INFINITY) lse += expf(logprobs[i] - mx);
+                if (wa_expf8_usable()) lse = wa_sum_expf8(logprobs + vocab.token_beg, n - vocab.token_beg, mx);
+                else for (int i = vocab.token_beg; i < n; ++i) if (logprobs[i] > -INFINITY) lse += expf(logprobs[i] - mx);
                 if (lse > 0.0f) ts_logprob = logf(lse) + mx;
             }
             const float max_text = max_f32(logprobs, vocab.token_beg);
             if (ts_logprob > max_text) for (int i = 0; i < vocab.token_beg; ++i) { logits[i] = -INFINITY; logprobs[i] = -INFINITY; }
         }
+        const int64_t tr1 = tr_on ? wa_time_us() : 0;
         if (full_probs) compute_probs(logits, n, logprobs, dec.probs.data());
         else compute_probs(logits + vocab.token_beg, n - vocab.token_beg, logprobs + vocab.token_beg, dec.probs.data() + vocab.token_beg);
+        if (tr_on && &dec == &st->decoders[0]) { const int64_t tr2 = wa_time_us(); tr_rules += tr1 - tr0; tr_probs += tr2 - tr1; }
     }
 
     // timestamp statistics shared by both samplers (whisper.cpp:6447-6465 / 6529-6547)
@@ -727,16 +737,20 @@ int runner::run(const float * samples, int n_samples) {
                         dec.sequence.tokens.push_back(sample_token(dec, t_cur < 1e-6f));
                         dec.sequence.sum_logprobs_all += dec.sequence.tokens.back().plog;
                     } else {
-                        for (const auto & tok : sample_token_topk(dec, p.beam_search.beam_size)) {
+                        const int64_t trk = tr_on ? wa_time_us() : 0;
+                        const auto drawn = sample_token_topk(dec, p.beam_search.beam_size);
+                        if (tr_on && j == 0) tr_topk += wa_time_us() - trk;
+                        for (const auto & tok : drawn) {
                             bc_per_dec[j].push_back({ j, dec.seek_delta, dec.has_ts, dec.sequence });
                             bc_per_dec[j].back().sequence.tokens.push_back(tok);
                             bc_per_dec[j].back().sequence.sum_logprobs_all += tok.plog;
                         }
                     }
                 });
+                const int64_t trb0 = tr_on ? wa_time_us() : 0;
                 beam_candidates.clear();
-                for (const auto & bc : bc_per_dec) {
-                    beam_candidates.insert(beam_candidates.end(), bc.begin(), bc.end());
+                for (auto & bc : bc_per_dec) {
+                    beam_candidates.insert(beam_candidates.end(), std::make_move_iterator(bc.begin()), std::make_move_iterator(bc.end()));
                     if (!bc.empty()) st->n_sample += 1;
                 }
 
@@ -767,6 +781,7 @@ int runner::run(const float * samples, int n_samples) {
                     }
                 }
 
+                const int64_t trb1 = tr_on ? wa_time_us() : 0;
                 // ---- per-decoder state machine (whisper.cpp:7297-7379) ----
                 for (int j = 0; j < n_dec; ++j) {
                     auto & dec = st->decoders[j];
@@ -797,6 +812,7 @@ int runner::run(const float * samples, int n_samples) {
                 {
                     bool all_done = true;
                     for (int j = 0; j < n_dec; ++j) if (!st->decoders[j].completed && !st->decoders[j].failed) all_done = false;
+                    if (tr_on) { tr_beam += trb1 - trb0; tr_state += wa_time_us() - trb1; tr_steps += 1; }
                     if (all_done) break;
                 }
                 st->t_sample_us += wa_time_us() - ts0;
@@ -867,6 +883,9 @@ int runner::run(const float * samples, int n_samples) {
                 }
             }
 
+            if (tr_on && tr_steps > 0)
+                fprintf(stderr, "[sample] %ld steps, decoder 0 (us per step): rules + log-soft-max %.1f  probabilities %.1f  top-k draws %.1f  beam bookkeeping %.1f  state machine %.1f\n", (long) tr_steps,
+                        (double) tr_rules / tr_steps, (double) tr_probs / tr_steps, (double) tr_topk / tr_steps, (double) tr_beam / tr_steps, (double) tr_state / tr_steps);
             {   // rank the sequences (whisper.cpp:7484-7517)
                 double best_score = -INFINITY;
                 for (int j = 0; j < n_dec; ++j) {

@@ -889,10 +889,29 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
 // final LayerNorm + logits = token_embedding . x for every token row (whisper.cpp:2820-2835): every workgroup, every wave; the embedding
 // rows stream from HBM into registers (two buffers of 24 steps: the loads of the next piece fly during the current one)
 // -------------------------------------------------------------------------------------------------
+// A workgroup's share of the logits: a CONTIGUOUS run of 8-row groups of the token embedding (so that its results leave as whole 256-byte
+// stores - also straight into pinned host memory, WHISPER_AMD_ROWS_HOST_OUT); wave w takes the groups g0 + w + 8 j.  Local row li = 8 (w + 8 j) + r.
+__device__ __forceinline__ int mb_share(int n_vocab, int * g1) {
+    const int NG = (n_vocab + 7) >> 3, gpw = (NG + (int) gridDim.x - 1) / (int) gridDim.x, g0 = (int) blockIdx.x * gpw;
+    *g1 = g0 + gpw < NG ? g0 + gpw : NG;
+    return g0;
+}
+// the staged rows (lg [BT][256], local rows < 256) -> the logits rows, 64 consecutive floats per store
+__device__ __forceinline__ void mb_logits_out(mb_kargs A, const float * lg, int B, int tid) {
+    int g1; const int g0 = mb_share(A->n_vocab, &g1), n_vocab = A->n_vocab;
+    GAS float * logits = (GAS float *) A->logits;
+    const int n_loc = (g1 - g0) * 8 < 256 ? (g1 - g0) * 8 : 256;
+    for (int idx = tid; idx < B * 256; idx += MB_THREADS) {
+        const int m = idx >> 8, t = idx & 255, row = g0 * 8 + t;
+        if (t < n_loc && row < n_vocab) logits[(size_t) m * n_vocab + row] = lg[m * 256 + t];
+    }
+}
+
 // the first piece of a wave's first embedding rows, asked for BEFORE the final LayerNorm waits for its row (piece 0 of mb_logits / mb_logits_q)
 __device__ __forceinline__ void mb_te_first(mb_kargs A, bool quant, unsigned (&buf)[48], int lane, int wave) {
     const int d = A->d, ns = d >> 5, n_vocab = A->n_vocab, u = lane & 7;
-    const int row = ((int) blockIdx.x + (int) gridDim.x * wave) * 8 + (lane >> 3), rc = row < n_vocab ? row : 0;
+    int g1_; const int g0_ = mb_share(n_vocab, &g1_);
+    const int row = (g0_ + wave) * 8 + (lane >> 3), rc = row < n_vocab ? row : 0;
     if (!quant) {
         const gch wrow = (gch) A->te + (size_t) rc * d + 4 * u;
 #pragma unroll
@@ -906,14 +925,15 @@ __device__ __forceinline__ void mb_te_first(mb_kargs A, bool quant, unsigned (&b
 }
 
 template <int BT>
-__device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /* rows of xs = logits rows */, int lane, int wave, unsigned (&pfa)[48], float * lg /* LDS [BT][256] or null */) {
+__device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /* rows of xs = logits rows */, int lane, int wave, unsigned (&pfa)[48], float * lg /* LDS [BT][256]: the staged share */) {
     const int d = A->d, ns = d >> 5, nbat = (ns + 23) / 24, n_vocab = A->n_vocab;
-    const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
+    const int u = lane & 7;
     GAS float * logits = (GAS float *) A->logits;
     unsigned pfb[48];
-    auto grp = [&](int j) { return wg + nwg * (wave + MB_NW * j); };
+    int g1; const int g0 = mb_share(n_vocab, &g1);
+    auto grp = [&](int j) { return g0 + wave + MB_NW * j; };
     int n_items = 0;
-    for (int j = 0; grp(j) < NG; ++j) n_items += nbat;
+    for (int j = 0; grp(j) < g1; ++j) n_items += nbat;
     auto load = [&](int it, unsigned (&buf)[48]) {
         const int j = it / nbat, bt = it - j * nbat, row = grp(j) * 8 + (lane >> 3);
         const gch wrow = (gch) A->te + (size_t) (row < n_vocab ? row : 0) * d + 4 * u;
@@ -959,8 +979,8 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
                     t[i] = v + dpp_f32<0x101>(v);
                 }
                 const float r = (t[0] + t[1]) + (t[2] + t[3]);
-                if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = r;
-                if (lg && u == 0 && j < 4) lg[m * 256 + (8 * j + wave) * 8 + (lane >> 3)] = r;
+                if (u == 0 && j < 4) lg[m * 256 + (8 * j + wave) * 8 + (lane >> 3)] = r;         // staged: mb_logits_out
+                else if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = r;   // (a share of more than 256 rows: the rest directly)
             }
         }
     };
@@ -979,12 +999,13 @@ __device__ __forceinline__ void mb_logits(mb_kargs A, const wa_f16 * xs, int B /
 template <int BT>
 __device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xop, size_t op_bytes, int B, int lane, int wave, unsigned (&pfa)[48], float * lg) {
     const int d = A->d, nb = d >> 5, nbat = (nb + 23) / 24, n_vocab = A->n_vocab;
-    const int nwg = gridDim.x, wg = blockIdx.x, NG = (n_vocab + 7) >> 3, u = lane & 7;
+    const int u = lane & 7;
     GAS float * logits = (GAS float *) A->logits;
     unsigned pfb[48];
-    auto grp = [&](int j) { return wg + nwg * (wave + MB_NW * j); };
+    int g1; const int g0 = mb_share(n_vocab, &g1);
+    auto grp = [&](int j) { return g0 + wave + MB_NW * j; };
     int n_items = 0;
-    for (int j = 0; grp(j) < NG; ++j) n_items += nbat;
+    for (int j = 0; grp(j) < g1; ++j) n_items += nbat;
     auto load = [&](int it, unsigned (&buf)[48]) {
         const int j = it / nbat, bt = it - j * nbat, row = grp(j) * 8 + (lane >> 3), rc = row < n_vocab ? row : 0;
         const GAS unsigned * wl = (const GAS unsigned *) A->te + ((size_t) rc * 8 + u) * nb;
@@ -1017,8 +1038,8 @@ __device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xo
             for (int m = 0; m < BT; ++m) {
                 float v = acc[m];
                 v = v + dpp_f32<0x104>(v); v = v + dpp_f32<0x102>(v); v = v + dpp_f32<0x101>(v);
-                if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = v;
-                if (lg && u == 0 && j < 4) lg[m * 256 + (8 * j + wave) * 8 + (lane >> 3)] = v;
+                if (u == 0 && j < 4) lg[m * 256 + (8 * j + wave) * 8 + (lane >> 3)] = v;
+                else if (u == 0 && row < n_vocab && m < B) logits[(size_t) m * n_vocab + row] = v;
             }
         }
     };
@@ -1088,7 +1109,7 @@ __device__ __forceinline__ void mb_pick(mb_kargs A, int b, int lane, int * pk, i
 // candidate records of logits row m (token row br) from this workgroup's share of the logits, kept in LDS by mb_logits (lg [BT][256]); all threads
 __device__ __forceinline__ void mb_record(mb_kargs A, int br, const float * lg_m, const int * pk, unsigned * scratch /* LDS [8][8] */, int tid) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nwg = gridDim.x, wg = blockIdx.x, n_vocab = A->n_vocab, beg = A->token_beg, eot = A->token_eot;
+    const int wg = blockIdx.x, n_vocab = A->n_vocab, beg = A->token_beg, eot = A->token_eot;
     const GAS unsigned * smask = (const GAS unsigned *) A->rows[br].smask;
     const int st_last = pk[1], st_penult = pk[2], st_seek = pk[3], st_has = pk[4];
     const bool last_ts = st_last >= beg, penult_ts = st_penult < 0 || st_penult >= beg;
@@ -1096,9 +1117,10 @@ __device__ __forceinline__ void mb_record(mb_kargs A, int br, const float * lg_m
     const int ts_min = st_has ? beg + st_seek / 2 : beg;
     mb_best bt = { -INFINITY, 0x7fffffff }, bs = { -INFINITY, 0x7fffffff };
     float s_ts = 0.0f;
-    if (tid < 256) {        // local row li = (8 j + wave') 8 + r8  <->  vocabulary row 8 (wg + nwg (wave' + 8 j)) + r8
-        const int li = tid, row = 8 * (wg + nwg * (((li >> 3) & 7) + 8 * (li >> 6))) + (li & 7);
-        if (row < n_vocab) {
+    int g1; const int g0 = mb_share(n_vocab, &g1);
+    if (tid < 256) {        // local row li  <->  vocabulary row 8 g0 + li (mb_share)
+        const int li = tid, row = 8 * g0 + li;
+        if (row < n_vocab && row < 8 * g1) {
             const float r = lg_m[li];
             const unsigned mw = smask[row >> 5];
             if (!((mw >> (row & 31)) & 1u)) {
@@ -1426,7 +1448,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     }
     bool want_rec = false;
     for (int m = 0; m < n_out; ++m) want_rec = want_rec || A->rows[A->out_row[m]].smask != nullptr;
-    float * lg = want_rec ? (float *) area : nullptr;            // (the gathered-inputs area holds nothing any more)
+    float * lg = (float *) area;            // (the gathered-inputs area holds nothing any more) the workgroup's logits, staged for whole-line stores and the records
     mb_barrier();
     if constexpr (Q) {
         if (n_out <= 2) mb_logits_q<2>(A, xinB, opB, n_out, lane, wave, pf0, lg); else if (n_out <= 4) mb_logits_q<4>(A, xinB, opB, n_out, lane, wave, pf0, lg);
@@ -1435,8 +1457,9 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         if (n_out <= 2) mb_logits<2>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg); else if (n_out <= 4) mb_logits<4>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg);
         else if (n_out <= 5) mb_logits<5>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg); else mb_logits<8>(A, (const wa_f16 *) xinB, n_out, lane, wave, pf0, lg);
     }
+    mb_barrier();
+    mb_logits_out(A, lg, n_out, tid);
     if (want_rec) {          // candidate records of every row that asked for them (the next pass of its chunk picks its token from them)
-        mb_barrier();
         for (int m = 0; m < n_out; ++m) {
             const int br = A->out_row[m];
             if (A->rows[br].smask) mb_record(A, br, lg + m * 256, pk + 8 * br, rscr, tid);
