@@ -346,9 +346,14 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
     unsigned * h_status = (unsigned *) (bst.h_logits_pinned + (size_t) WA_MAX_DECODERS * hp.n_vocab);      // (the staging buffer has 64 spare words)
     std::unique_lock<std::mutex> lk(mega_slot(ctx.device), std::defer_lock);
     if (wait_slot) lk.lock(); else if (!lk.try_lock()) return 0;
+    // the logits rows go straight into the pinned staging rows (whole-line stores, wa_rows.hip: mb_logits_out); WHISPER_AMD_ROWS_HOST_OUT=0: device rows + a copy
+    static const bool host_out_env = getenv("WHISPER_AMD_ROWS_HOST_OUT") == nullptr || atoi(getenv("WHISPER_AMD_ROWS_HOST_OUT")) != 0;
+    float * h_dev = nullptr;
+    const bool host_out = host_out_env && hipHostGetDevicePointer((void **) &h_dev, bst.h_logits_pinned, 0) == hipSuccess && h_dev;
+    if (host_out) a.logits = h_dev;
     (void) hipMemsetAsync(bst.d_rows_status + 4, 0, WA_ROWS_MAX * sizeof(unsigned), s);
     if (!wa_launch_decode_rows(s, a, n_wg)) { bst.rows_enabled = false; return 0; }
-    (void) hipMemcpyAsync(bst.h_logits_pinned, bst.d_logits, (size_t) n_out * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (!host_out) (void) hipMemcpyAsync(bst.h_logits_pinned, bst.d_logits, (size_t) n_out * hp.n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     (void) hipMemcpyAsync(h_status, bst.d_rows_status, 12 * sizeof(unsigned), hipMemcpyDeviceToHost, s);
     if (!WA_HIP_OK(hipStreamSynchronize(s))) { bst.rows_enabled = false; return 0; }
     lk.unlock();
@@ -993,9 +998,12 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     if (n_rows) (void) hipMemcpyAsync(st.h_logits_pinned, st.d_logits, (size_t) n_rows * n_vocab * sizeof(float), hipMemcpyDeviceToHost, s);
     if (!WA_HIP_OK(hipStreamSynchronize(s))) return false;
     }
-    if (!from_batcher)       // (the batcher delivered its row straight into st.logits)
-    for (int r = 0; r < n_rows; ++r)
-        memcpy(st.logits.data() + (size_t) h_rows[r] * n_vocab, st.h_logits_pinned + (size_t) r * n_vocab, n_vocab * sizeof(float));
+    st.staged_n = 0;
+    if (!from_batcher) {     // (the batcher delivered its row straight into st.logits)
+        if (st.defer_rows && n_rows > 1) { st.staged_n = n_rows; st.staged_of.assign(h_rows, h_rows + n_rows); }      // the caller's per-decoder threads fetch them
+        else for (int r = 0; r < n_rows; ++r)
+            memcpy(st.logits.data() + (size_t) h_rows[r] * n_vocab, st.h_logits_pinned + (size_t) r * n_vocab, n_vocab * sizeof(float));
+    }
 
     const int64_t dt = wa_time_us() - t0;
     if (n_tokens == 1)       { st.t_decode_us += dt; st.n_decode++; }

@@ -278,7 +278,9 @@ int wrap_segment(whisper_context * ctx, whisper_state * st, int max_len, bool sp
     return (int) starts.size();
 }
 
-struct beam_candidate { int decoder_idx; int seek_delta; bool has_ts; wa_sequence sequence; };
+// a beam candidate = the sequence of decoder `decoder_idx` as it stands + one drawn token (the reference copies the whole sequence into every
+// candidate, whisper.cpp:7218-7224; here only the decoders that survive get one built)
+struct beam_candidate { int decoder_idx; int seek_delta; bool has_ts; whisper_token_data tok; double sum_logprobs_all; };
 
 bool same_tokens(const wa_sequence & a, const wa_sequence & b) {   // whisper.cpp:6419-6430
     if (a.tokens.size() != b.tokens.size()) return false;
@@ -395,6 +397,9 @@ struct runner {
         const int n = n_vocab;
         dec.logits.resize(n); dec.probs.resize(n); dec.logprobs.resize(n);
         float * logits = dec.logits.data();
+        if (st->staged_n > 0)       // this decoder's row is still in the staging rows of the pass (wa_decode: defer_rows): it goes into state->logits here, on this thread
+            for (int r = 0; r < st->staged_n; ++r)
+                if (st->staged_of[r] == dec.i_batch) memcpy(st->logits.data() + (size_t) dec.i_batch * n, st->h_logits_pinned + (size_t) r * n, n * sizeof(float));
         memcpy(logits, st->logits.data() + (size_t) dec.i_batch * n, n * sizeof(float));
         if (temperature > 0.0f) for (int i = 0; i < n; ++i) logits[i] /= temperature;
 
@@ -741,36 +746,48 @@ int runner::run(const float * samples, int n_samples) {
                         const auto drawn = sample_token_topk(dec, p.beam_search.beam_size);
                         if (tr_on && j == 0) tr_topk += wa_time_us() - trk;
                         for (const auto & tok : drawn) {
-                            bc_per_dec[j].push_back({ j, dec.seek_delta, dec.has_ts, dec.sequence });
-                            bc_per_dec[j].back().sequence.tokens.push_back(tok);
-                            bc_per_dec[j].back().sequence.sum_logprobs_all += tok.plog;
+                            double sum_all = dec.sequence.sum_logprobs_all;
+                            sum_all += tok.plog;
+                            bc_per_dec[j].push_back({ j, dec.seek_delta, dec.has_ts, tok, sum_all });
                         }
                     }
                 });
                 const int64_t trb0 = tr_on ? wa_time_us() : 0;
                 beam_candidates.clear();
                 for (auto & bc : bc_per_dec) {
-                    beam_candidates.insert(beam_candidates.end(), std::make_move_iterator(bc.begin()), std::make_move_iterator(bc.end()));
+                    beam_candidates.insert(beam_candidates.end(), bc.begin(), bc.end());
                     if (!bc.empty()) st->n_sample += 1;
                 }
 
                 // ---- beam search: keep the best candidates, re-label KV cells (whisper.cpp:7239-7291) ----
                 if (p.strategy == WHISPER_SAMPLING_BEAM_SEARCH) {
                     std::sort(beam_candidates.begin(), beam_candidates.end(), [](const beam_candidate & a, const beam_candidate & b) {
-                        if (a.sequence.sum_logprobs_all != b.sequence.sum_logprobs_all) return a.sequence.sum_logprobs_all > b.sequence.sum_logprobs_all;
+                        if (a.sum_logprobs_all != b.sum_logprobs_all) return a.sum_logprobs_all > b.sum_logprobs_all;
                         return a.decoder_idx < b.decoder_idx;
                     });
+                    // two candidates spell the same sequence: the same new token behind equal token ids so far (whisper.cpp:6419-6430)
+                    auto same_candidate = [&](const beam_candidate & a, const beam_candidate & b) {
+                        return a.tok.id == b.tok.id && (a.decoder_idx == b.decoder_idx || same_tokens(st->decoders[a.decoder_idx].sequence, st->decoders[b.decoder_idx].sequence));
+                    };
                     uint32_t cur_c = 0;
+                    std::vector<wa_sequence> next(n_dec);        // built from the decoders' sequences as they stand; swapped in once all are chosen
                     for (int j = 0; j < n_dec; ++j) {
                         auto & dec = st->decoders[j];
                         if (dec.completed || dec.failed) continue;
                         if (cur_c >= beam_candidates.size()) cur_c = 0;
-                        auto & cur = beam_candidates[cur_c++];
-                        while (beam_candidates.size() > cur_c && same_tokens(beam_candidates[cur_c].sequence, cur.sequence) && i > 0) ++cur_c;
+                        const auto & cur = beam_candidates[cur_c++];
+                        while (beam_candidates.size() > cur_c && same_candidate(beam_candidates[cur_c], cur) && i > 0) ++cur_c;
                         dec.seek_delta = cur.seek_delta;
                         dec.has_ts = cur.has_ts;
-                        dec.sequence = cur.sequence;
+                        next[j] = st->decoders[cur.decoder_idx].sequence;
+                        next[j].tokens.push_back(cur.tok);
+                        next[j].sum_logprobs_all = cur.sum_logprobs_all;
                         wa_kv_seq_cp(st->kv_self, cur.decoder_idx, WA_MAX_DECODERS + j, -1, -1);
+                    }
+                    for (int j = 0; j < n_dec; ++j) {
+                        auto & dec = st->decoders[j];
+                        if (dec.completed || dec.failed) continue;
+                        std::swap(dec.sequence, next[j]);
                     }
                     for (int j = 0; j < n_dec; ++j) {
                         auto & dec = st->decoders[j];
@@ -872,13 +889,17 @@ int runner::run(const float * samples, int n_samples) {
                             ov.on = false;
                         }
                     }
-                    if (!have_logits && !wa_decode(*ctx, *st, b, false, p.abort_callback, p.abort_callback_user_data)) { WA_ERROR("%s: failed to decode\n", __func__); return -9; }
+                    st->defer_rows = b.n_tokens > 1;        // (every row of this batch belongs to a live decoder, whose process_logits below fetches it)
+                    const bool dec_ok = have_logits || wa_decode(*ctx, *st, b, false, p.abort_callback, p.abort_callback_user_data);
+                    st->defer_rows = false;
+                    if (!dec_ok) { st->staged_n = 0; WA_ERROR("%s: failed to decode\n", __func__); return -9; }
                     const int64_t ts1 = wa_time_us();
                     par_for(n_dec, [&](int j) {
                         auto & dec = st->decoders[j];
                         if (dec.failed || dec.completed) return;
                         process_logits(dec, t_cur, need_full_probs);
                     });
+                    st->staged_n = 0;
                     st->t_sample_us += wa_time_us() - ts1;
                 }
             }

@@ -132,7 +132,17 @@ struct whisper_context {
 // ---------------------------------------------------------------------------------------------
 // KV cell bookkeeping (ref: whisper.cpp:725-750, 1049-1167). Metadata only; data lives in HBM.
 // ---------------------------------------------------------------------------------------------
-struct wa_kv_cell { int32_t pos = -1; std::set<int32_t> seq_id; bool has(int32_t s) const { return seq_id.count(s) != 0; } };
+// the sequence ids a cell belongs to (whisper.cpp:1049-1167 keeps a std::set per cell; the ids here are decoder indices and their scratch
+// twins, < 2 WA_MAX_DECODERS): one word - beam search relabels every cell of every live decoder four times per step
+struct wa_seq_set {
+    uint64_t bits = 0;
+    void insert(int32_t s) { if (s >= 0 && s < 64) bits |= 1ull << s; }
+    void erase(int32_t s)  { if (s >= 0 && s < 64) bits &= ~(1ull << s); }
+    void clear() { bits = 0; }
+    bool empty() const { return bits == 0; }
+    size_t count(int32_t s) const { return s >= 0 && s < 64 && ((bits >> s) & 1ull) ? 1 : 0; }
+};
+struct wa_kv_cell { int32_t pos = -1; wa_seq_set seq_id; bool has(int32_t s) const { return seq_id.count(s) != 0; } };
 
 struct wa_kv_cache {
     uint32_t head = 0, size = 0, n = 0;
@@ -274,6 +284,11 @@ struct whisper_state {
     long n_rows_steps = 0, n_rows_fallback = 0;      // passes served by the one-launch form / sent to the launch sequence after a status
     struct wa_batcher * batcher = nullptr;   // set while this state is a member of a whisper_amd_full_batch call (wa_decode.cpp)
     bool solo_step = false;                  // the next plain step of a lock-step member is decoded by the member alone (its row of a pass asked to be redone by the launch sequence)
+    // several logits rows of one pass (beam search, best_of): with `defer_rows` set by the caller wa_decode leaves them in the pinned staging rows and every
+    // decoder's own host thread moves its row into `logits` (wa_full.cpp: process_logits) - five 207 KB copies side by side instead of one after the other
+    bool defer_rows = false;
+    int  staged_n = 0;
+    std::vector<int32_t> staged_of;      // staged_of[r] = batch index of staging row r
     bool spec_owner = false;                 // this state holds its device's one-launch slot (wa_spec_begin .. wa_spec_end)
     hipEvent_t ev_k[2] = { nullptr, nullptr }, ev_c[2] = { nullptr, nullptr };
     int n_spec_ok = 0, n_spec_miss = 0;
