@@ -23,6 +23,7 @@ import wsynth
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def digest(a):
@@ -413,3 +414,21 @@ def test_full_batch_with_chunks_that_leave_early(wrs, amd_lib, gold):
             assert [(s["t0"], s["t1"], s["ids"], s["p"], s["plog"]) for s in got] == [(s["t0"], s["t1"], s["ids"], s["p"], s["plog"]) for s in want[i]], i
             st.free()
     ctx.free()
+
+
+@pytest.mark.parametrize("shape", ["s128", "s128:q5_0"])
+def test_environment_switches_do_not_change_a_bit(shape):
+    """"results are bit-identical under every combination" of the backend's switches.  They are read once per process, so one
+    process per combination (tools/switch_check.py: four chunks in a lock-step group, greedy, beam 5, best_of 3 with the ladder -> one digest)."""
+    import subprocess, sys
+    combos = [{}, {"WHISPER_AMD_ROWS_HOST_OUT": "0"}, {"WHISPER_AMD_NO_RUN_AHEAD": "1"}, {"WHISPER_AMD_NO_ROWS": "1"}, {"WHISPER_AMD_NO_BATCHER": "1"},
+              {"WHISPER_AMD_NO_MEGA": "1", "WHISPER_AMD_NO_ROWS": "1"}, {"WHISPER_AMD_NO_OVERLAP": "1"}]
+    lines = []
+    for env_extra in combos:
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "switch_check.py"), shape], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (env_extra, r.stdout[-400:], r.stderr[-800:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("digest")]
+        assert line, (env_extra, r.stdout[-400:])
+        lines.append(line[-1])
+    assert len(set(lines)) == 1, list(zip([str(c) for c in combos], lines))

@@ -54,18 +54,21 @@ def rows_roofline(lib, ctx, states, shape, B, n_past, same_chunk, bytes_per_weig
     n_chunks = 1 if same_chunk else len({s.ptr for s in states[:B]})
     nbytes = int(_dec_weight_bytes(shape, bytes_per_weight) + n_chunks * kvx + B * kvs)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC counters where this very shape was collected (tools/profile_gpu_r03.sh -> profiles/r03_rows_and_quant_pmc.json:
-    # ggml-small, 8 rows of 8 chunks / 5 rows of one chunk, n_past 110; 2 x FETCH_SIZE + WRITE_SIZE) - off-line, not in this run
-    traffic = None
-    try:
-        import json
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r03_rows_and_quant_pmc.json")))
-        key = "rows8" if (B == 8 and not same_chunk) else "rows5" if (B == 5 and same_chunk) else None
-        if key and shape["d"] == 768 and bytes_per_weight == 2.0:
-            traffic = int(pj[key]["traffic_MB_per_launch"] * 1e6)
-    except Exception:
-        traffic = None
-    return {"bound": "hbm", "traffic_source": "profiles/r03_rows_and_quant_pmc.json (collected off-line at n_past 110)" if traffic else None, "kernel": "k_decode_rows: %d token rows in ONE persistent launch (wa_rows.hip), n_past=%d, %s" %
+    # HBM bytes per launch from the PMC counters where this very shape was collected (tools/profile_gpu_r03b.sh -> profiles/r03_rows_pmc.json, the kernel's final
+    # state; r03_rows_and_quant_pmc.json is the earlier collection: ggml-small, 8 rows of 8 chunks at n_past 110 / 5 rows of one chunk; 2 x FETCH_SIZE + WRITE_SIZE)
+    # - off-line, not in this run
+    traffic = src = None
+    for fn in ("r03_rows_pmc.json", "r03_rows_and_quant_pmc.json"):
+        try:
+            import json
+            pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            key = "rows8" if (B == 8 and not same_chunk) else "rows5" if (B == 5 and same_chunk) else None
+            if key and shape["d"] == 768 and bytes_per_weight == 2.0:
+                traffic = int(pj[key]["traffic_MB_per_launch"] * 1e6); src = "profiles/%s (collected off-line)" % fn
+                break
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return {"bound": "hbm", "traffic_source": src, "kernel": "k_decode_rows: %d token rows in ONE persistent launch (wa_rows.hip), n_past=%d, %s" %
                                       (B, n_past, "rows of one chunk (beams)" if same_chunk else "%d different chunks" % n_chunks),
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "bytes_per_step": nbytes, "ms_per_step_device": round(ms, 4)}
