@@ -581,38 +581,43 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
     float mx = red[0];
 #pragma unroll
     for (int k = 1; k < MB_NW; ++k) mx = fmaxf(mx, red[k]);
-    // ---- soft_max exactly as ops.cpp:4792-4818 + vec.cpp:257-308 (k_attn_exact) ----
+    // ---- soft_max exactly as ops.cpp:4792-4818 + vec.cpp:257-308 (k_attn_exact): a thread per cell - exp, the group sums by the reference's 8-lane tree over
+    //      DPP (as the cross-attention unit), F64 partial sums; ONE barrier, then every thread forms the same total from the eight wave sums ----
     const int n8 = n_kv & ~7, ng = n8 >> 3;
-    for (int cc = tid; cc < n_kv; cc += MB_THREADS) sc[cc] = cc < n8 ? wa_expf(sc[cc] - mx) : wa_expf_libm(sc[cc] - mx);
-    mb_barrier();
-    for (int g = tid; g < ng; g += MB_THREADS) {
-        const float * v = &sc[g * 8];
-        gs[g] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
-    }
-    mb_barrier();
+    float inv;
     {
         double ps = 0.0;
-        for (int g = tid; g < ng; g += MB_THREADS) ps += (double) gs[g];
-        for (int cc = n8 + tid; cc < n_kv; cc += MB_THREADS) ps += (double) sc[cc];
+        for (int c0 = 0; c0 < n_kv; c0 += MB_THREADS) {       // (uniform trip count: every lane takes part in the DPP exchanges)
+            const int cc = c0 + tid;
+            const bool in = cc < n_kv;
+            const float e = !in ? 0.0f : cc < n8 ? wa_expf(sc[cc] - mx) : wa_expf_libm(sc[cc] - mx);
+            if (in) sc[cc] = e;
+            float t = e + dpp_f32<0x104>(e);        // lanes r = 0..3 of the group: e[r] + e[r+4]
+            t = t + dpp_f32<0x102>(t);
+            t = t + dpp_f32<0x101>(t);              // r = 0: ((e0+e4)+(e2+e6)) + ((e1+e5)+(e3+e7)), ops.cpp's tree
+            if (in) {
+                if (cc < n8) { if ((tid & 7) == 0) { gs[cc >> 3] = t; ps += (double) t; } }
+                else ps += (double) e;              // (the n % 8 tail cells: any order, the total is certified below)
+            }
+        }
         ps = wave_sum_d(ps);
         if (lane == 0) redd[wave] = ps;
         mb_barrier();
-        if (tid == 0) {
-            double sum = 0.0;
-#pragma unroll
-            for (int w = 0; w < MB_NW; ++w) sum += redd[w];
-            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
-            const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
-            if (ilo != ihi) {       // (~1e-9 per soft-max) the reference's order
-                sum = 0.0;
-                for (int g = 0; g < ng; ++g) sum += (double) gs[g];
-                for (int cc = n8; cc < n_kv; ++cc) sum += (double) sc[cc];
-                *s_inv = (float) (1.0 / sum);
-            } else *s_inv = ilo;
+        const double sum = ((redd[0] + redd[1]) + (redd[2] + redd[3])) + ((redd[4] + redd[5]) + (redd[6] + redd[7]));
+        const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
+        const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
+        inv = ilo;
+        if (ilo != ihi) {       // (~1e-9 per soft-max; the same for every thread) the reference's order, by one thread
+            if (tid == 0) {
+                double so = 0.0;
+                for (int g = 0; g < ng; ++g) so += (double) gs[g];
+                for (int cc = n8; cc < n_kv; ++cc) so += (double) sc[cc];
+                *s_inv = (float) (1.0 / so);
+            }
+            mb_barrier();
+            inv = *s_inv;
         }
-        mb_barrier();
     }
-    const float inv = *s_inv;
     for (int cc = tid; cc < n_kv; cc += MB_THREADS) p16[cc] = f2h(sc[cc] * inv);
     const int np = n_kv & ~31, nsteps = np >> 5, nl = n_kv - np;
     if (tid < 256) {        // the leftover cells' V rows -> LDS
