@@ -36,6 +36,10 @@ bw = np.zeros(4)
 for l in range(L):
     bw += np.array([t[l*32+14]-t[l*32+4], t[l*32+27]-t[l*32+6], t[l*32+15]-t[l*32+11], t[l*32+28]-t[l*32+13]]) / 100.0
 print("wait at the barrier in front of the products (mean): out %.2f  cq %.2f  fc1 %.2f  fc2 %.2f" % tuple(bw / L))
+ln = np.zeros(3)
+for l in range(1, L): ln += np.array([t[l*32+29]-t[l*32], t[l*32+30]-t[l*32+29], t[l*32+1]-t[l*32+30]]) / 100.0
+print("LN1 (mean over layers >= 1): wait for the row %.2f  sums + mean certificate %.2f  squares, normalise, store + barrier %.2f" % tuple(ln / max(1, L - 1)))
+print("LN1 rows of the traced wave whose variance went through the in-order sum: %d of %d layers" % (sum(1 for l in range(1, L) if t[l*32+31] != 0), L - 1))
 print("mean   : " + "  ".join("%s %.2f" % (n, x) for n, x in zip(names, tot / L)) + "   | %.1f us per layer" % (tot.sum() / L))
 print("final LayerNorm + logits: %.1f us;  whole step %.1f us" % ((t[L * 32 + 1] - t[L * 32]) / 100.0, (t[L * 32 + 1] - t[0]) / 100.0))
 

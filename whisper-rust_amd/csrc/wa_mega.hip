@@ -786,7 +786,7 @@ __device__ __forceinline__ void mg_role_gemv(mg_kargs A_, int idx_) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const mg_kargs A = mg_uniform(A_);
     int lane = threadIdx.x & 63;
-#define MG_FRESH() do { if constexpr (Q) lane = mq_fresh(lane); } while (0)      /* see mq_fresh: nothing lane-derived lives across phases */
+#define MG_FRESH() do { lane = mq_fresh(lane); } while (0)      /* see mq_fresh: nothing lane-derived lives across phases */
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = __builtin_amdgcn_readfirstlane(idx_), nG = (int) gridDim.x - 5 * A->n_head;
     mg_ctl c; c.status = (gu32 *) A->status; c.seq = A->seq; c.dead = false;

@@ -318,7 +318,11 @@ __device__ __forceinline__ double mb_seq_sum(const float (&xv)[NP], int d, bool 
 }
 template <int NP, bool Q = false>         // Q: the normalised row leaves as Q8_0 (the next product's operand), not as F16
 __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_row /* null: embeddings */, const float * lnp /* LDS: gamma | beta, each d floats in whole KB */, const float * gw_g, const float * gb_g /* global, when non-null */,
-                                          int b, int lane, wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code, int token = 0) {
+                                          int b, int lane_, wa_f16 * dst, float * xres_b, int row_d, int r_d, unsigned code, int token = 0, bool tw = false, int tslot = 0) {
+    // (nothing derived from the lane index may live across calls: hoisted out of the layer loop the per-element LDS addresses went to scratch, and every
+    //  reload waits for the vector-memory queue)
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
     const int d = A->d;
     float xv[NP];
     if (edge_row) {
@@ -348,6 +352,7 @@ __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_ro
             for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k; if (i >= row_d && i < row_d + r_d && i < d) xres_b[i - row_d] = xv[k]; }
         }
     }
+    mb_trace(A, tw, tslot);          // (timeline: the row is in)
     double s = 0.0, a = 0.0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) { s += (double) xv[k]; a += (double) fabsf(xv[k]); }
@@ -374,21 +379,30 @@ __device__ __forceinline__ void mb_ln_row(mb_kargs A, mb_ctl & c, gu64 * edge_ro
             else { s = mb_seq_sum<NP>(xv, d, false, 0.0f); mean = (float) (s / (double) d); }
         }
     }
+    mb_trace(A, tw, tslot + 1);      // (the mean is certified)
     double s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) if (lane + 64 * k < d) { const float t = xv[k] - mean; s2 += (double) (t * t); }
     s2 = wave_sum_d(s2);
     float variance;
-    if (!wa_sum_certain(s2, s2, d, variance, A->rn_d)) { s2 = mb_seq_sum<NP>(xv, d, true, mean); variance = (float) (s2 / (double) d); }
+    if (!wa_sum_certain(s2, s2, d, variance, A->rn_d)) { mb_trace(A, tw, tslot + 2); s2 = mb_seq_sum<NP>(xv, d, true, mean); variance = (float) (s2 / (double) d); }
     const float scale = 1.0f / sqrtf(variance + A->eps);
+    // gamma | beta: from LDS (wave 7 brought them), or - the first LayerNorm of a launch - from global memory; one uniform branch around the loads
+    float gam[NP], bet[NP];
+    if (gw_g) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : 0; gam[k] = ((gcf) gw_g)[ic]; bet[k] = ((gcf) gb_g)[ic]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { const int i = lane + 64 * k, ic = i < d ? i : 0; gam[k] = lnp[ic]; bet[k] = lnp[((d + 255) & ~255) + ic]; }      // (beta: behind gamma's whole LDS-DMA pieces)
+    }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int i = lane + 64 * k;
         float y = xv[k] - mean;
         y = y * scale;
-        const int ic = i < d ? i : 0;
-        y = y * (gw_g ? ((gcf) gw_g)[ic] : lnp[ic]);
-        y = y + (gb_g ? ((gcf) gb_g)[ic] : lnp[((d + 255) & ~255) + ic]);      // (beta: behind gamma's whole LDS-DMA pieces)
+        y = y * gam[k];
+        y = y + bet[k];
         if constexpr (!Q) { if (i < d) dst[i] = f2h(y); }
         else {                  // a half-wave holds one 32-element block (d % 64 == 0: every block of k < d / 64 is whole)
             float dq;
@@ -544,13 +558,16 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
         for (int i = 0; i < 8; ++i) { qa[i] = h2f(qs[8 * a + i]); qb[i] = h2f(qs[32 + 8 * a + i]); }
         for (int c0 = 0; c0 < n_kv; c0 += (MB_THREADS / 4) * 4) {
             u32x4 ka[4], kb[4];
-            int8_t mk[4];
+            int8_t mk[4] = { 0, 0, 0, 0 };
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 int cc = c0 + p * (MB_THREADS / 4) + kslot; cc = cc < n_kv ? cc : n_kv - 1;
                 if (c0 == 0) { ka[p] = ka0[p]; kb[p] = kb0[p]; }
                 else { ka[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 8 * a); kb[p] = *(const GAS u32x4 *) (kp + (size_t) cc * d + 32 + 8 * a); }
-                mk[p] = mrow ? mrow[cc] : (int8_t) 0;
+            }
+            if (mrow) {         // (ONE uniform branch around the four loads: as a select per element every load was issued and waited for on its own - also without a mask)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { int cc = c0 + p * (MB_THREADS / 4) + kslot; cc = cc < n_kv ? cc : n_kv - 1; mk[p] = mrow[cc]; }
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -1306,8 +1323,18 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_T(0);
         MB_CHAOS_AT(27u);
         // ---------------- P1: LayerNorm + q|k|v ----------------
-        if (wave < B) mb_ln_row<NP, Q>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, l == 0 ? Y.ln1_w : nullptr, l == 0 ? Y.ln1_b : nullptr,
-                                       wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), xres + wave * 8, row_d, r_d, 100u + l, pk[8 * wave]);
+        // F16 kernels: two instances of the first LayerNorm - layer 0 (embedding rows, gamma | beta from global memory) and the others (granules, LDS).  As ONE
+        // instance with run-time choices the layers >= 1 paid 4-8 us for code they never run (medium, 5 rows: 12.9 -> 5.1 us; a 5-row pass 1.80 -> 1.65 ms).  The
+        // quantised kernels keep one instance: they are short of registers (99-198 spilled VGPRs) and a second copy cost more than it won (large-v3-q5_0: 3.22 -> 3.65 ms).
+        if (wave < B) {
+            if constexpr (Q) {
+                mb_ln_row<NP, Q>(A, c, l == 0 ? nullptr : mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, l == 0 ? Y.ln1_w : nullptr, l == 0 ? Y.ln1_b : nullptr,
+                                 wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), xres + wave * 8, row_d, r_d, 100u + l, pk[8 * wave], tw, l * 32 + 29);
+            } else {
+                if (l == 0) mb_ln_row<NP, Q>(A, c, nullptr, lnp, Y.ln1_w, Y.ln1_b, wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), xres + wave * 8, row_d, r_d, 100u, pk[8 * wave]);
+                else        mb_ln_row<NP, Q>(A, c, mb_edge(A, l - 1, E_X3) + (size_t) wave * RG, lnp, nullptr, nullptr, wave, lane, (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 100u + l, 0, tw, l * 32 + 29);
+            }
+        }
         MB_T(1);
         run_phase(l, 0, [&](const mb_phase & ph, const unsigned char * slot, int row_base, int Rc, int) {
             gu64 * eq = mb_edge(A, l, E_QKV);
@@ -1448,8 +1475,13 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
     mb_te_first(A, Q, pf0, lane, wave);
     if (wave < n_out) {
         const int br = A->out_row[wave];
-        mb_ln_row<NP, Q>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, lnp, L > 0 ? nullptr : A->lnf_w, L > 0 ? nullptr : A->lnf_b, br, lane,
-                         (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 3000u, pk[8 * br]);
+        if constexpr (Q) {
+            mb_ln_row<NP, Q>(A, c, L > 0 ? mb_edge(A, L - 1, E_X3) + (size_t) br * RG : nullptr, lnp, L > 0 ? nullptr : A->lnf_w, L > 0 ? nullptr : A->lnf_b, br, lane,
+                             (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 3000u, pk[8 * br]);
+        } else {
+            if (L > 0) mb_ln_row<NP, Q>(A, c, mb_edge(A, L - 1, E_X3) + (size_t) br * RG, lnp, nullptr, nullptr, br, lane, (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 3000u);
+            else       mb_ln_row<NP, Q>(A, c, nullptr, lnp, A->lnf_w, A->lnf_b, br, lane, (wa_f16 *) (xinB + (size_t) wave * opB), nullptr, 0, 0, 3000u, pk[8 * br]);      // (a model without layers: tests)
+        }
     }
     bool want_rec = false;
     for (int m = 0; m < n_out; ++m) want_rec = want_rec || A->rows[A->out_row[m]].smask != nullptr;
