@@ -1401,7 +1401,8 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_CHAOS_WG(23u); MB_CHAOS_AT(24u);
         // a (row, head) in 4 quarters.  (Two halves - where the quarters of all rows need a second round on part of the grid, B H 4 > workgroups - were
         // built (mb_unit_cross<Q, 2>) and measured: the 144 registers of a half's keys / values push the whole kernel into scratch (463 spilled
-        // registers; 5 rows 0.67 -> 0.78 ms, 8 rows 0.92 -> 1.06 ms per step), the half itself took 22 us against 2 x 9.8 for two rounds of quarters.)
+        // registers; 5 rows 0.67 -> 0.78 ms, 8 rows 0.92 -> 1.06 ms per step), the half itself took 22 us against 2 x 9.8 for two rounds of quarters.  Tried again once
+        // the kernel was free of scratch (mb_ln_row's opaque lane): ~30 spilled registers, a half takes 17 us = two quarters, 8 rows 0.863 -> 0.877 ms: no.)
         for (int u = wg; u < B * H * 4; u += nwg) {
             const int bh = u >> 2;
             mb_cross_regs<4> CR;    // (asked for here: earlier - across the cross-query products - the 72 registers cost those products 2 us and won 0.8)
