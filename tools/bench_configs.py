@@ -55,10 +55,10 @@ def rows_roofline(lib, ctx, states, shape, B, n_past, same_chunk, bytes_per_weig
     nbytes = int(_dec_weight_bytes(shape, bytes_per_weight) + n_chunks * kvx + B * kvs)
     gbs = nbytes / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters where this very shape was collected (tools/profile_gpu_r03b.sh -> profiles/r03_rows_pmc.json, the kernel's final
-    # state; r03_rows_and_quant_pmc.json is the earlier collection: ggml-small, 8 rows of 8 chunks at n_past 110 / 5 rows of one chunk; 2 x FETCH_SIZE + WRITE_SIZE)
+    # state: ggml-small, 8 rows of 8 chunks at n_past 110 / 5 rows of one chunk at n_past 64; 2 x FETCH_SIZE + WRITE_SIZE)
     # - off-line, not in this run
     traffic = src = None
-    for fn in ("r03_rows_pmc.json", "r03_rows_and_quant_pmc.json"):
+    for fn in ("r03_rows_pmc.json",):
         try:
             import json
             pj = json.load(open(os.path.join(ROOT, "profiles", fn)))

@@ -1,6 +1,5 @@
 #!/bin/bash
-# Round-3 profiles at the final code state (runs on the GPU box under gpurun; the decode-step PMC collections of tools/profile_gpu_r03.sh stay valid:
-# wa_mega.hip did not change after them).  Kernel statistics, the HBM counters of the several-rows kernel (one counter per pass, --kernel-trace
+# Round-3 profiles at the final code state (runs on the GPU box under gpurun).  Kernel statistics, the HBM counters of the single-token step (three collections), the HBM counters of the several-rows kernel (one counter per pass, --kernel-trace
 # only), the kernel timeline of a lock-step group and the in-kernel timelines.  Summaries land in gpurun_out/prof3b/ and are copied to profiles/ by hand.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -18,6 +17,10 @@ for cfg in "8 chunks 110" "5 beams 64"; do set -- $cfg
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/quant_rows -- python3 $ROOT/tools/rows_probe.py small:q5_0 5 beams 30 64 > $OUT/quant_rows.log 2>&1 || true
 find $OUT/quant_rows -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/quant_rows_kernel_stats.csv
+echo "== HBM traffic counters of the single-token step (three collections)"; date
+for rep in 1 2 3; do for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_mega_${c}_$rep -- python3 $ROOT/tools/decode_probe.py small 20 64 0 > $OUT/pmc_mega_${c}_$rep.log 2>&1 || true
+done; done
 echo "== HBM traffic counters of the several-rows kernel"; date
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_rows8_$c -- python3 $ROOT/tools/rows_probe.py small 8 chunks 10 110 > $OUT/pmc_rows8_$c.log 2>&1 || true
@@ -33,6 +36,25 @@ def collect(dirpat, kernel, counter):
             if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                 vals.append(float(row["Counter_Value"]))
     return vals
+import statistics
+reps = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    reps[c] = []
+    for rep in (1, 2, 3):
+        v = collect("pmc_mega_%s_%d" % (c, rep), "k_decode_mega", c)
+        if v: reps[c].append(sum(v) / len(v))
+mega = {"kernel": "k_decode_mega (ggml-small shape, 1 token, n_past = 64)",
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/decode_probe.py small 20 64 0 (tools/profile_gpu_r03b.sh; one counter per pass, three collections)",
+        "FETCH_SIZE_KB_per_launch": statistics.median(reps["FETCH_SIZE"]) if reps["FETCH_SIZE"] else None,
+        "WRITE_SIZE_KB_per_launch": statistics.median(reps["WRITE_SIZE"]) if reps["WRITE_SIZE"] else None,
+        "FETCH_SIZE_KB_collections": reps["FETCH_SIZE"], "WRITE_SIZE_KB_collections": reps["WRITE_SIZE"],
+        "traffic_MB_min_median_max": None,
+        "note": "gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md, HBM): read bytes = 2 x FETCH_SIZE x 1024 for wide streams"}
+if len(reps["FETCH_SIZE"]) == 3 and len(reps["WRITE_SIZE"]) == 3:
+    t = sorted((2 * f + w) * 1024 / 1e6 for f, w in zip(sorted(reps["FETCH_SIZE"]), sorted(reps["WRITE_SIZE"])))
+    mega["traffic_MB_min_median_max"] = [round(t[0], 1), round(t[1], 1), round(t[2], 1)]
+json.dump(mega, open(os.path.join(out, "decode_step_pmc.json"), "w"), indent=1)
+print(json.dumps(mega)[:500])
 rows = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/rows_probe.py small 8 chunks 10 110 | small 5 beams 10 64 (tools/profile_gpu_r03b.sh)",
         "note": "gfx950: read bytes = 2 x FETCH_SIZE x 1024 for wide streams (MI355X_MICROARCH.md, HBM); traffic = that + WRITE_SIZE x 1024, per launch"}
 for tag in ("rows8", "rows5"):
@@ -45,7 +67,7 @@ PY
 echo "== kernel timeline of a lock-step group of 8 chunks"; date
 rocprofv3 --kernel-trace --output-format csv -d $OUT/c8 -- python3 $ROOT/tools/chunks8_probe.py small 8 3 > $OUT/c8.log 2>&1 || true
 ( echo "# rocprofv3 --kernel-trace -- python3 tools/chunks8_probe.py small 8 3 ; python3 tools/chunks8_probe.py - - - <trace dir>   (tools/profile_gpu_r03b.sh)"; grep "^rep" $OUT/c8.log; python3 $ROOT/tools/chunks8_probe.py - - - $OUT/c8 ) > $OUT/chunks8_timeline.txt 2>&1 || true
-rm -rf $OUT/c8 $OUT/stats $OUT/rows_8 $OUT/rows_5 $OUT/quant_rows $OUT/pmc_rows8_FETCH_SIZE $OUT/pmc_rows8_WRITE_SIZE $OUT/pmc_rows5_FETCH_SIZE $OUT/pmc_rows5_WRITE_SIZE
+rm -rf $OUT/c8 $OUT/stats $OUT/rows_8 $OUT/rows_5 $OUT/quant_rows $OUT/pmc_rows8_FETCH_SIZE $OUT/pmc_rows8_WRITE_SIZE $OUT/pmc_rows5_FETCH_SIZE $OUT/pmc_rows5_WRITE_SIZE $OUT/pmc_mega_*_[123]
 echo "== in-kernel timelines"; date
 cd $ROOT
 ( echo "# WHISPER_AMD_ROWS_TRACE=0 python3 tools/rows_trace.py small 8 110"; WHISPER_AMD_ROWS_TRACE=0 python3 tools/rows_trace.py small 8 110; echo; echo "# WHISPER_AMD_ROWS_TRACE=0 python3 tools/rows_trace.py small 5 64"; WHISPER_AMD_ROWS_TRACE=0 python3 tools/rows_trace.py small 5 64 ) > $OUT/rows_trace.txt 2>&1 || true
