@@ -8,6 +8,7 @@ two libraries are interchangeable behind one binding.
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -213,3 +214,31 @@ def test_rust_sys_tree_builds_and_links_like_build_rs(tmp_path):
                            "-lggml-hip", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lpthread", "-lm", "-Wl,-rpath,/opt/rocm/lib"])
     got = subprocess.check_output([exe]).decode().split()
     assert got[:5] == ["5", "1", "1", "296", "48"], got
+
+
+def test_one_launch_kernels_use_no_scratch(tmp_path):
+    """The persistent decode kernels must not touch scratch memory: a spilled register is reloaded behind `s_waitcnt vmcnt(0)`, i.e. behind the wave's
+    outstanding weight loads (addresses hoisted out of the layer loop into scratch cost a tenth of every pass until round 3).  Read from the
+    code objects the build just made (AMDGPU metadata: private_segment_fixed_size, vgpr_spill_count).  k_decode_mega_q is exempt: its d = 1280 instantiation
+    is known to spill ("what is left")."""
+    tools = "/opt/rocm/lib/llvm/bin"
+    objs = [os.path.join(ROOT, "whisper-rust_amd", "build", n) for n in ("wa_rows_12.o", "wa_rows_16.o", "wa_rows_20.o", "wa_mega.o")]
+    if not all(os.path.exists(o) for o in objs) or not os.path.exists(os.path.join(tools, "clang-offload-bundler")):
+        pytest.skip("no build tree / LLVM tools here")
+    seen = {}
+    for o in objs:
+        fat, co = str(tmp_path / "fat"), str(tmp_path / "co")
+        subprocess.check_call([os.path.join(tools, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, o])
+        subprocess.check_call([os.path.join(tools, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
+        notes = subprocess.check_output([os.path.join(tools, "llvm-readelf"), "--notes", co], text=True)
+        name = None
+        for line in notes.splitlines():
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split(":", 1)[1].strip()
+            elif name and (line.startswith(".private_segment_fixed_size:") or line.startswith(".vgpr_spill_count:")):
+                seen.setdefault(name, {})[line.split(":")[0]] = int(line.split(":")[1])
+    kernels = [k for k in seen if "k_decode_rows" in k or k.startswith("_Z13k_decode_mega")]
+    assert len(kernels) == 7, sorted(seen)
+    for k in kernels:
+        assert seen[k] == {".private_segment_fixed_size": 0, ".vgpr_spill_count": 0}, (k, seen[k])
