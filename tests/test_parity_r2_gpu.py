@@ -432,3 +432,27 @@ def test_environment_switches_do_not_change_a_bit(shape):
         assert line, (env_extra, r.stdout[-400:])
         lines.append(line[-1])
     assert len(set(lines)) == 1, list(zip([str(c) for c in combos], lines))
+
+
+@pytest.mark.parametrize("shape", ["s128", "s128:q5_0"])
+def test_lockstep_group_with_chunks_of_several_windows(wrs, amd_lib, shape):
+    """Members of a lock-step group whose audio spans several 30 s windows (45 s, 70 s, 30 s, 100 s): they encode again in the middle of the group's life,
+    leave their run-ahead windows and open new ones at different times, finish at different times.  Each chunk's segments must equal its solo run's."""
+    mp = wsynth.quant_model_path(*shape.split(":")) if ":" in shape else wsynth.model_path(shape)
+    ctx = wrs.WhisperContext.new_with_params(mp, wrs.WhisperContextParameters(amd_lib), lib=amd_lib)
+    lens = [45, 70, 30, 100]
+    pcms = [wsynth.synth_audio(16000 * n, 40 + i) for i, n in enumerate(lens)]
+    fp = wrs.FullParams(amd_lib, 0, best_of=1, temperature_inc=0.0)
+    solo = []
+    for p in pcms:
+        st = ctx.create_state(); st.full(fp, p); solo.append(_segs(st)); st.free()
+    states = [ctx.create_state() for _ in pcms]
+    wrs.full_batch(ctx, states, fp, pcms)
+    for i, st in enumerate(states):
+        assert _segs(st) == solo[i], (shape, lens[i])
+        st.free()
+    steps, rows = C.c_long(), C.c_long()
+    amd_lib.whisper_amd_batch_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    amd_lib.whisper_amd_batch_stats(ctx.ptr, steps, rows)
+    assert steps.value > 50 and rows.value > steps.value, (steps.value, rows.value)      # passes really were shared
+    ctx.free()
