@@ -313,7 +313,8 @@ def _full_depth(wrs, amd_lib, ref_lib, mp, d, n_mels_note):
         assert digest(sa.get_logits_last(len(toks))) == digest(sr.get_logits_last(len(toks))), (toks, n_past)
     assert amd_lib.whisper_amd_mega_enabled(sa.ptr) == 1
     served, back = sa.rows_stats()
-    assert served == 2 and back == 0, (served, back)          # the prompt and the 5-token batch
+    # the prompt and the 5-token batch - and, for a wide quantised model, the single token too (its step is the several-rows kernel with one row: wa_internal.h)
+    assert served == (3 if ("q5_0" in n_mels_note and d > 768) else 2) and back == 0, (served, back)
     for x_ in (sa, sr):
         x_.free()
     a.free(); r.free()

@@ -177,15 +177,21 @@ def config5(W, lib, ref, hip, nthr, with_cpu=True):
     # decode-step roofline: Q5_0 weights at 22 bytes per 32 (550.3 + 245.8 MB for large-v3)
     st = a.create_state()
     st.pcm_to_mel(wsynth.synth_audio(480000, 0)); st.encode(0)
+    # (a wide quantised model's single-token step IS the several-rows kernel with one row - wa_internal.h: single_via_rows -, k_decode_mega_q is timed beside it)
     ms = C.c_float()
     lib.whisper_amd_decode_step_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
-    if lib.whisper_amd_decode_step_probe(a.ptr, st.ptr, 64, 50, C.byref(ms)) == 0 and ms.value > 0:
+    mega_ms = ms.value if lib.whisper_amd_decode_step_probe(a.ptr, st.ptr, 64, 50, C.byref(ms)) == 0 and ms.value > 0 else None
+    rows_ms, _rc = _probe_rows(lib, a, [st], 1, 64, 50)
+    step_ms = min(x for x in (mega_ms, rows_ms) if x) if (mega_ms or rows_ms) else None
+    if step_ms:
         kvx, kvs = _kv_bytes(shape, 64)
         nbytes = int(_dec_weight_bytes(shape, 22.0 / 32.0) + kvx + kvs)
-        gbs = nbytes / (ms.value * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_decode_mega_q: the single-token decoder pass of a quantised model as one launch, n_past=64",
+        gbs = nbytes / (step_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": ("k_decode_rows_q_np20 with one token row" if rows_ms and step_ms == rows_ms else "k_decode_mega_q") +
+                                                     ": the single-token decoder pass of a quantised model as one launch, n_past=64",
                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                           "bytes_per_step": nbytes, "ms_per_step_device": round(ms.value, 4)}
+                           "bytes_per_step": nbytes, "ms_per_step_device": round(step_ms, 4),
+                           "ms_k_decode_mega_q": round(mega_ms, 4) if mega_ms else None, "ms_k_decode_rows_q_one_row": round(rows_ms, 4) if rows_ms else None}
     st.free()
     if with_cpu and ref is not None:
         r = W.WhisperContext.new_with_params(mp, W.WhisperContextParameters(ref, use_gpu=False), lib=ref)

@@ -48,7 +48,7 @@ for step, tok in enumerate(toks):
     g1 = np.zeros(L * 8 * 2 * d, dtype=np.uint64); l1 = np.zeros(nv, dtype=np.float32)
     rc = lib.whisper_amd_mega_debug(ctx.ptr, meg.ptr, tok, n_past, g1.ctypes.data, l1.ctypes.data)
     g1 = g1.reshape(L, 8, 2 * d)
-    for B in (2, 5, 8):
+    for B in (1, 2, 5, 8):
         gB = np.zeros(L * 8 * B * 2 * d, dtype=np.uint64); lB = np.zeros(B * nv, dtype=np.float32)
         rcB = lib.whisper_amd_rows_debug(ctx.ptr, meg.ptr, B, tok, n_past, gB.ctypes.data, lB.ctypes.data)
         gB = gB.reshape(L, 8, B, 2 * d); lB = lB.reshape(B, nv)

@@ -417,8 +417,47 @@ void wa_spec_end(whisper_context & ctx, whisper_state & st) {
     if (st.spec_owner) { st.spec_owner = false; mega_slot(ctx.device).unlock(); }      // idempotent: only the owner gives the slot back
 }
 
+// the window's launch for a state whose single-token step is the several-rows kernel with one row (single_via_rows): same records, sampling state and
+// suppression bits as the k_decode_mega form; behind the logits: [n_vocab] status, [+1] the launch's sequence number, [+2] the token decoded, [+4] the row's status
+static bool spec_launch_rows(whisper_context & ctx, whisper_state & st, int k, int pos, int token, const wa_spec_state & after) {
+    const auto & m = ctx.model; const auto & hp = m.hp;
+    const int T = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
+    const int n_wg = std::min(m.n_cu, 256), quant = m.wtype != 1 ? 1 : 0, n_kv = pos + 1;
+    if (!st.rows_enabled || st.rows_pause > 0 || n_kv > WA_ROWS_MAXKV || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
+    wa_rows_args a;
+    memset(&a, 0, sizeof(a));
+    if (wa_rows_lds_bytes(hp.n_text_state, 1, n_wg, quant, &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, st)) return false;
+    const int b = k & 1;
+    a.layers = (const wa_mega_layer *) m.d_mega_layers;
+    a.n_layer = hp.n_text_layer; a.d = hp.n_text_state; a.n_head = hp.n_text_head; a.n_vocab = hp.n_vocab; a.eps = hp.eps; a.rn_d = 1.0 / (double) hp.n_text_state;
+    a.te = m.d_te; a.pe = m.d_pe; a.lnf_w = m.d_ln.w; a.lnf_b = m.d_ln.b; a.gelu = m.d_gelu; a.quant = quant;
+    if (quant) { a.te = (const wa_f16 *) m.te_q.qs; a.te_d = m.te_q.qd; }
+    a.kv_layer_stride = (unsigned long long) st.kv_self.size * hp.n_text_state;
+    a.cross_layer_stride = (unsigned long long) hp.n_text_head * st.cross_tpad * 64; a.cross_tpad = st.cross_tpad; a.T = T;
+    a.granules = st.d_rows_gr; a.row_gr = 2 * hp.n_text_state; a.cross_gr = st.d_rows_cgr;
+    a.logits = b ? st.d_mega_out2 : st.d_mega_out;
+    a.status = (unsigned *) (a.logits + hp.n_vocab); a.tok_out = (int *) (a.logits + hp.n_vocab + 2); a.row_status = (unsigned *) (a.logits + hp.n_vocab + 4);
+    a.kq_scale = pow(float(64), -0.25); a.B = 1; a.n_out = 1; a.out_row[0] = 0;
+    a.token_beg = ctx.vocab.token_beg; a.token_eot = ctx.vocab.token_eot;
+    wa_rows_row & r = a.rows[0];
+    r.kv_k = st.kv_self.k; r.kv_v = st.kv_self.v; r.cross_k = st.d_cross_k; r.cross_v = st.d_cross_v; r.mask = nullptr;
+    r.n_kv = n_kv; r.kv_head = pos; r.token = token < 0 ? 0 : token; r.pos = pos;       // greedy steady state: cell == position
+    r.spec = token < 0 ? 1 : 0;
+    r.rec_in = st.d_mega_rec[b ^ 1]; r.rec_out = st.d_mega_rec[b]; r.ps_in = (const int *) st.d_mega_ps[b ^ 1]; r.ps_out = (int *) st.d_mega_ps[b]; r.smask = st.d_mega_smask;
+    r.s_last = after.last; r.s_penult = after.penult; r.s_seek_delta = after.seek_delta; r.s_has_ts = after.has_ts;
+    st.mega_seq += 1; if (st.mega_seq == 0) st.mega_seq = 1;
+    a.seq = st.mega_seq;
+    (void) hipMemsetAsync(a.row_status, 0, sizeof(unsigned), st.stream);
+    if (!wa_launch_decode_rows(st.stream, a, n_wg)) { st.rows_enabled = false; st.single_via_rows = false; return false; }
+    st.spec_seq[b] = a.seq;
+    // (on the launch's own stream: beside the next launch of THIS kernel a copy on another stream gets no CU until that launch has finished - wa_batcher)
+    (void) hipMemcpyAsync(st.h_spec[b], a.logits, ((size_t) hp.n_vocab + 8) * sizeof(float), hipMemcpyDeviceToHost, st.stream);
+    return WA_HIP_OK(hipEventRecord(st.ev_c[b], st.stream));
+}
+
 bool wa_spec_launch(whisper_context & ctx, whisper_state & st, int k, int pos, int token, const wa_spec_state & after) {
     if (st.batcher) return bspec_launch(*st.batcher, st, k, pos, token, after);
+    if (st.single_via_rows) return spec_launch_rows(ctx, st, k, pos, token, after);
     wa_mega_args a;
     if (!mega_args(ctx, st, a, token < 0 ? 0 : token, pos, pos + 1, pos)) return false;       // greedy steady state: cell == position
     const int b = k & 1;
@@ -446,8 +485,10 @@ int wa_spec_wait(whisper_context & ctx, whisper_state & st, int k, int * token_u
     const int b = k & 1, n_vocab = ctx.model.hp.n_vocab;
     if (!WA_HIP_OK(hipEventSynchronize(st.ev_c[b]))) { st.mega_enabled = false; return -1; }
     unsigned status = ((const unsigned *) st.h_spec[b])[n_vocab];
-    if (status == 0 && ((const unsigned *) st.h_spec[b])[n_vocab + 2] != st.spec_seq[b]) status = 9999u;      // the launch never ran: not this step's logits
-    if (token_used) *token_used = ((const int *) st.h_spec[b])[n_vocab + 1];
+    const int i_echo = st.single_via_rows ? 1 : 2, i_tok = st.single_via_rows ? 2 : 1;          // (spec_launch_rows: the words behind the logits)
+    if (status == 0 && ((const unsigned *) st.h_spec[b])[n_vocab + i_echo] != st.spec_seq[b]) status = 9999u;      // the launch never ran: not this step's logits
+    if (status == 0 && st.single_via_rows && ((const unsigned *) st.h_spec[b])[n_vocab + 4] != 0) status = WA_MEGA_REDO;
+    if (token_used) *token_used = ((const int *) st.h_spec[b])[n_vocab + i_tok];
     st.t_decode_us += wa_time_us() - t0; st.n_decode++;
     if (status != 0) {
         wa_spec_drain(ctx, st);
@@ -947,7 +988,13 @@ bool wa_decode(whisper_context & ctx, whisper_state & st, const wa_batch & batch
     const bool solo = st.solo_step; st.solo_step = false;
     const bool device_free = wa_encoders_in_flight(ctx.device).load(std::memory_order_relaxed) == 0;      // (wa_internal.h: no one-launch step beside encoder passes)
     if (steady && st.batcher && !solo) done = from_batcher = batcher_step(*st.batcher, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
-    if (!done && steady && st.mega_enabled && st.mega_pause > 0) st.mega_pause -= 1;      // (paused after a time-out: this pass takes the launch sequence)
+    if (!done && steady && st.single_via_rows && device_free) {        // a wide quantised model: the several-rows kernel with ONE row (wa_internal.h: single_via_rows)
+        const wa_rows_row r1 = { kv.k, kv.v, st.d_cross_k, st.d_cross_v, nullptr, n_kv, kv_head, h_tok[0], h_pos[0] };
+        const int T1 = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
+        done = rows_step(ctx, st, 1, &r1, 1, nullptr, T1, st.cross_tpad, kv.size, st.batcher == nullptr) == 1;
+    }
+    if (done) { }
+    else if (!done && steady && st.mega_enabled && st.mega_pause > 0) st.mega_pause -= 1;      // (paused after a time-out: this pass takes the launch sequence)
     else if (!done && steady && st.mega_enabled && device_free) done = mega_step(ctx, st, h_tok[0], h_pos[0], n_kv, kv_head) == 1;
     if (!done && !steady && n_tokens <= WA_ROWS_MAX && n_rows >= 1 && !save_aheads && st.rows_enabled && n_kv <= WA_ROWS_MAXKV && device_free) {
         // one token per live decoder (beam search, best_of, the bench's small batches): all rows in ONE launch (wa_rows.hip)

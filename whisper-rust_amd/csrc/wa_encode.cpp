@@ -119,6 +119,9 @@ bool wa_state_alloc(whisper_context & ctx, whisper_state & st) {
                 const char * r = getenv("WHISPER_AMD_NO_ROWS");
                 int slot = 0;
                 st.rows_enabled = !(r && r[0] == '1') && wa_rows_lds_bytes(dt, 2, std::min(ctx.model.n_cu, 256), ctx.model.wtype != 1 ? 1 : 0, &slot) != 0;
+                const char * sr = getenv("WHISPER_AMD_SINGLE_ROWS");
+                st.single_via_rows = st.rows_enabled && wa_rows_lds_bytes(dt, 1, std::min(ctx.model.n_cu, 256), ctx.model.wtype != 1 ? 1 : 0, &slot) != 0 &&
+                                     (sr ? sr[0] == '1' : (ctx.model.wtype != 1 && dt > 768));
             }
             // (the copy stream, events and pinned buffers of the host overlap are created on first use, wa_spec_begin: a state that
             //  only ever runs inside whisper_amd_full_batch keeps ONE stream - extra streams cost the concurrent chunks their overlap)

@@ -286,6 +286,9 @@ struct whisper_state {
     bool solo_step = false;                  // the next plain step of a lock-step member is decoded by the member alone (its row of a pass asked to be redone by the launch sequence)
     // several logits rows of one pass (beam search, best_of): with `defer_rows` set by the caller wa_decode leaves them in the pinned staging rows and every
     // decoder's own host thread moves its row into `logits` (wa_full.cpp: process_logits) - five 207 KB copies side by side instead of one after the other
+    // wide quantised models (d > 768): the single-token step runs on the several-rows kernel with ONE row - it streams its weights through LDS-DMA and has no
+    // spilled prefetch registers (large-v3-q5_0: 2.04 ms against k_decode_mega_q's 2.31); WHISPER_AMD_SINGLE_ROWS=0 / 1 overrides
+    bool single_via_rows = false;
     bool defer_rows = false;
     int  staged_n = 0;
     std::vector<int32_t> staged_of;      // staged_of[r] = batch index of staging row r
