@@ -40,6 +40,10 @@ ln = np.zeros(3)
 for l in range(1, L): ln += np.array([t[l*32+29]-t[l*32], t[l*32+30]-t[l*32+29], t[l*32+1]-t[l*32+30]]) / 100.0
 print("LN1 (mean over layers >= 1): wait for the row %.2f  sums + mean certificate %.2f  squares, normalise, store + barrier %.2f" % tuple(ln / max(1, L - 1)))
 print("LN1 rows of the traced wave whose variance went through the in-order sum: %d of %d layers" % (sum(1 for l in range(1, L) if t[l*32+31] != 0), L - 1))
+sn = ["entry", "q|k|v in", "barrier", "scores + max", "barrier", "soft-max", "p16 + leftover V, barrier", "P V", "finish", "barrier"]
+su = np.zeros(9)
+for l in range(L): su += np.diff(t[4096 + l * 16:4096 + l * 16 + 10]) / 100.0
+print("self unit (mean): " + "  ".join("%s>%s %.2f" % (sn[i], sn[i + 1], x) for i, x in enumerate(su / L)))
 print("mean   : " + "  ".join("%s %.2f" % (n, x) for n, x in zip(names, tot / L)) + "   | %.1f us per layer" % (tot.sum() / L))
 print("final LayerNorm + logits: %.1f us;  whole step %.1f us" % ((t[L * 32 + 1] - t[L * 32]) / 100.0, (t[L * 32 + 1] - t[0]) / 100.0))
 

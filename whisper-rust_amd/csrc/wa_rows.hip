@@ -490,7 +490,9 @@ __device__ __forceinline__ void mb_attn_finish(const float * part, const wa_f16 
 // its cache (earlier tokens of a small batch; other beams, which the mask hides) - arrive as granules, like the query.
 // -------------------------------------------------------------------------------------------------
 template <bool Q = false>
-__device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int tid) {
+__device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned char * area, int l, int b, int h, int tid, bool tw = false) {
+#define MB_TS(k) mb_trace(A, tw, 4096 + l * 16 + (k))
+    MB_TS(0);
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float  * part = (float *) area;                                  // [32][64]
     float  * sc   = (float *) (area + 8192);                         // [MAXKV]
@@ -541,7 +543,9 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
         }
         if (lane == 0) ncl[wave] = same && A->rows[wave].kv_head < n_kv ? A->rows[wave].kv_head : -1;
     } else if (lane == 0) ncl[wave] = -1;
+    MB_TS(1);
     mb_barrier();
+    MB_TS(2);
     int nc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) nc[j] = __builtin_amdgcn_readfirstlane(ncl[j]);
@@ -571,6 +575,7 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
+                if (c0 + p * (MB_THREADS / 4) >= n_kv) break;       // (uniform: a block of 128 cells behind the row's last one - with 110 cells three of the four)
                 const int cc = c0 + p * (MB_THREADS / 4) + kslot;
                 float r = mb_score(ka[p], kb[p], qa, qb, 1.0f);
                 if (cc < n_kv && new_of(cc) < 0) {       // (a cell written by this launch: below, from its granules)
@@ -594,7 +599,9 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
     }
     lmax = wave_max(lmax);
     if (lane == 0) red[wave] = lmax;
+    MB_TS(3);
     mb_barrier();
+    MB_TS(4);
     float mx = red[0];
 #pragma unroll
     for (int k = 1; k < MB_NW; ++k) mx = fmaxf(mx, red[k]);
@@ -635,6 +642,7 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
             inv = *s_inv;
         }
     }
+    MB_TS(5);
     for (int cc = tid; cc < n_kv; cc += MB_THREADS) p16[cc] = f2h(sc[cc] * inv);
     const int np = n_kv & ~31, nsteps = np >> 5, nl = n_kv - np;
     if (tid < 256) {        // the leftover cells' V rows -> LDS
@@ -645,6 +653,7 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
         }
     }
     mb_barrier();
+    MB_TS(6);
     // ---- P V: chains r = cell mod 32 (4 per wave), lane = d_head index ----
     {
         float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -670,9 +679,13 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
 #pragma unroll
         for (int i = 0; i < 4; ++i) part[(r0 + i) * 64 + lane] = acc[i];
     }
+    MB_TS(7);
     mb_barrier();
     mb_attn_finish<Q>(part, vleft, p16 + np, nl, mb_edge(A, l, E_AO) + (size_t) b * A->row_gr, h, c.seq, tid);
+    MB_TS(8);
     mb_barrier();
+    MB_TS(9);
+#undef MB_TS
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1359,7 +1372,7 @@ __device__ __forceinline__ void mb_body(mb_kargs A_) {
         MB_T(2);
         // ---------------- P2: self-attention ----------------
         MB_CHAOS_WG(20u); MB_CHAOS_AT(21u);
-        for (int u = wg; u < B * H; u += nwg) mb_unit_self<Q>(A, c, area, l, u / H, u % H, tid);
+        for (int u = wg; u < B * H; u += nwg) mb_unit_self<Q>(A, c, area, l, u / H, u % H, tid, tw);
         MB_T(3);
         // ---------------- P3: out-projection + residual ----------------
         MB_CHAOS_AT(22u);
