@@ -423,7 +423,9 @@ def test_environment_switches_do_not_change_a_bit(shape):
     process per combination (tools/switch_check.py: four chunks in a lock-step group, greedy, beam 5, best_of 3 with the ladder -> one digest)."""
     import subprocess, sys
     combos = [{}, {"WHISPER_AMD_ROWS_HOST_OUT": "0"}, {"WHISPER_AMD_NO_RUN_AHEAD": "1"}, {"WHISPER_AMD_NO_ROWS": "1"}, {"WHISPER_AMD_NO_BATCHER": "1"},
-              {"WHISPER_AMD_NO_MEGA": "1", "WHISPER_AMD_NO_ROWS": "1"}, {"WHISPER_AMD_NO_OVERLAP": "1"}]
+              {"WHISPER_AMD_NO_MEGA": "1", "WHISPER_AMD_NO_ROWS": "1"}, {"WHISPER_AMD_NO_OVERLAP": "1"}, {"WHISPER_AMD_SINGLE_ROWS": "1"},
+              # ... and the test build whose one-launch kernels stall waves and workgroups at random (lock-step passes running ahead, windows, beams under stalls)
+              {"WA_LIB": os.path.join(ROOT, "whisper-rust_amd", "libwhisper_chaos.so")}]
     lines = []
     for env_extra in combos:
         env = dict(os.environ); env.update(env_extra)
