@@ -934,6 +934,9 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attn_exact(const wa_f16 * __res
 // 110 MB of P per layer travel through HBM (< 20 us); one query per block (the VALU form above) re-read K and V from L2 instead.
 // -------------------------------------------------------------------------------------------------
 #define AS_Q 16
+#ifndef AS_PAD
+#define AS_PAD 4                                             // (was 8: rows 4 apart then start 32 banks = 0 banks apart - a 2-way conflict on every score store)
+#endif
 #define AS_THREADS 512                                       // 8 waves: two per SIMD (the score tiles of one hide the other's loads and LDS trips)
 typedef float as_f16v __attribute__((ext_vector_type(16)));
 
@@ -941,7 +944,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * 
                                                                  wa_f16 * __restrict__ p_left, int kvp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char as_smem[];
     float * sc = (float *) as_smem;                                     // [16][kvs] scores, then exponentials
-    const int kvs = kvp + 8;                                            // row stride: the four rows of a wave land on different banks
+    const int kvs = kvp + AS_PAD;                                       // row stride: the rows 4 fb + j of the four lane groups of a store land 16 banks apart (kvp % 32 == 0)
     __shared__ float red[AS_THREADS / 64][AS_Q];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, j0 = blockIdx.y * AS_Q;
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(AS_THREADS) void k_attn_scores_mfma(const wa_f16 * 
 void wa_launch_attn_exact_mfma(hipStream_t s, const wa_f16 * qk, int ldqk, const wa_f16 * vt, int ldvt, int T, int d, int n_head, float scale,
                                wa_f16 * p, wa_f16 * p_left, int kvp, wa_f16 * out, int ldo, float * out32) {
     static bool attr_done = false;
-    const int lds = AS_Q * (kvp + 8) * (int) sizeof(float);
+    const int lds = AS_Q * (kvp + AS_PAD) * (int) sizeof(float);
     if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_attn_scores_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096); attr_done = true; }
     hipLaunchKernelGGL(k_attn_scores_mfma, dim3(n_head, (T + AS_Q - 1) / AS_Q), dim3(AS_THREADS), lds, s, qk, ldqk, d, T, scale, p, p_left, kvp);
     const int np = T & ~31;
