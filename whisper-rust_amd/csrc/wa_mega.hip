@@ -1305,7 +1305,9 @@ __device__ __forceinline__ void mg_role_self(mg_kargs A_, int idx_) {
             if (lane == 0) M.redd[wave] = ps;
             mg_barrier();
             const double tot = ((M.redd[0] + M.redd[1]) + (M.redd[2] + M.redd[3])) + ((M.redd[4] + M.redd[5]) + (M.redd[6] + M.redd[7]));
-            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
+            // (the reference adds the ng + (n % 8) addends one after the other in F64: error <= (ng + 7) u S; this sum is a tree of depth <= 16 over the SAME addends:
+            //  error <= 16 u S; together (ng + 8 + 16) u S - not twice the reference's bound, which sent twice as many soft-maxes back to the launch sequence)
+            const double delta = (double) (ng + 8 + 16) * 0x1p-53 * tot * 1.000001;
             const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
             if (ilo != ihi && tid == 0 && !c.dead) __hip_atomic_store(c.status, (unsigned) WA_MEGA_REDO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tid < n_kv) M.p16[tid] = f2h(e * ilo);
@@ -1496,7 +1498,9 @@ __device__ __forceinline__ void mg_role_cross(mg_kargs A_, int idx_) {
                 const unsigned lo = __builtin_amdgcn_readlane(v[0], 2 * k), hi = __builtin_amdgcn_readlane(v[0], 2 * k + 1);
                 tot += __longlong_as_double((long long) (((u64) hi << 32) | lo));
             }
-            const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
+            // (the reference adds the ng + (n % 8) addends one after the other in F64: error <= (ng + 7) u S; this sum is a tree of depth <= 16 over the SAME addends:
+            //  error <= 16 u S; together (ng + 8 + 16) u S - not twice the reference's bound, which sent twice as many soft-maxes back to the launch sequence)
+            const double delta = (double) (ng + 8 + 16) * 0x1p-53 * tot * 1.000001;
             const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
             if (ilo != ihi && lane == 0 && !c.dead) __hip_atomic_store(c.status, (unsigned) WA_MEGA_REDO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (lane == 0) bc[1] = ilo;

@@ -628,7 +628,9 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
         if (lane == 0) redd[wave] = ps;
         mb_barrier();
         const double sum = ((redd[0] + redd[1]) + (redd[2] + redd[3])) + ((redd[4] + redd[5]) + (redd[6] + redd[7]));
-        const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * sum * 1.000001;
+        // (the reference adds the ng + (n % 8) addends one after the other in F64: error <= (ng + 7) u S; this sum is a tree of depth <= 16 over the SAME addends:
+        //  error <= 16 u S; together (ng + 8 + 16) u S - not twice the reference's bound, which sent twice as many soft-maxes back to the launch sequence)
+        const double delta = (double) (ng + 8 + 16) * 0x1p-53 * sum * 1.000001;
         const float ilo = (float) (1.0 / (sum + delta)), ihi = (float) (1.0 / (sum - delta));
         inv = ilo;
         if (ilo != ihi) {       // (~1e-9 per soft-max; the same for every thread) the reference's order, by one thread
@@ -822,7 +824,7 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
             const unsigned lo = __builtin_amdgcn_readlane(v[0], 2 * k), hi = __builtin_amdgcn_readlane(v[0], 2 * k + 1);
             tot += __longlong_as_double((long long) (((u64) hi << 32) | lo));
         }
-        const double delta = 2.0 * (double) (ng + 8) * 0x1p-53 * tot * 1.000001;
+        const double delta = (double) (ng + 8 + 16) * 0x1p-53 * tot * 1.000001;      // (as in the self-attention unit: reference (ng + 7) u S + this tree's 16 u S)
         const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
         if (ilo != ihi && lane == 0) ((GAS unsigned *) A->row_status)[b] = (unsigned) WA_MEGA_REDO;      // (this row only: the pass goes on)
         if (lane == 0) bc[1] = ilo;
