@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "whisper-rust_amd"))
 import wsynth, whisper_rs as W
 name = sys.argv[1] if len(sys.argv) > 1 else "small"
-lib = W.load_library(); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
+lib = W.load_library(os.environ.get("WA_LIB")); W.set_log_callback(lib, lambda l, t: sys.stderr.write(t) if l >= 3 else None)
 pcm = wsynth.synth_audio(480000, 0)
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 for flash in ([True, False] if len(sys.argv) < 3 else [bool(int(sys.argv[2]))]):
