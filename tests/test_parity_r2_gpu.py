@@ -425,7 +425,10 @@ def test_environment_switches_do_not_change_a_bit(shape):
     combos = [{}, {"WHISPER_AMD_ROWS_HOST_OUT": "0"}, {"WHISPER_AMD_NO_RUN_AHEAD": "1"}, {"WHISPER_AMD_NO_ROWS": "1"}, {"WHISPER_AMD_NO_BATCHER": "1"},
               {"WHISPER_AMD_NO_MEGA": "1", "WHISPER_AMD_NO_ROWS": "1"}, {"WHISPER_AMD_NO_OVERLAP": "1"}, {"WHISPER_AMD_SINGLE_ROWS": "1"},
               # ... and the test build whose one-launch kernels stall waves and workgroups at random (lock-step passes running ahead, windows, beams under stalls)
-              {"WA_LIB": os.path.join(ROOT, "whisper-rust_amd", "libwhisper_chaos.so")}]
+              {"WA_LIB": os.path.join(ROOT, "whisper-rust_amd", "libwhisper_chaos.so")},
+              # ... and every cross soft-max total of the several-rows kernel through its in-order path (otherwise taken ~3e-5 of the time), also under stalls
+              {"WHISPER_AMD_ROWS_FORCE_INORDER": "1"},
+              {"WHISPER_AMD_ROWS_FORCE_INORDER": "1", "WA_LIB": os.path.join(ROOT, "whisper-rust_amd", "libwhisper_chaos.so")}]
     lines = []
     for env_extra in combos:
         env = dict(os.environ); env.update(env_extra)

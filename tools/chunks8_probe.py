@@ -26,8 +26,8 @@ def timeline(d):
     gap = [(rows[b][0] - rows[a][1]) / 1e3 for a, b in zip(last, last[1:])]
     print("rows-kernel launches in the last repetition: %d; duration mean %.1f us (min %.1f, max %.1f); gap between consecutive launches mean %.1f us (median %.1f, max %.1f)"
           % (len(last), sum(dur) / len(dur), min(dur), max(dur), sum(gap) / max(1, len(gap)), sorted(gap)[len(gap) // 2] if gap else 0, max(gap) if gap else 0))
-    big = sorted(gap)[-8:]
-    print("largest gaps (us):", ["%.0f" % g for g in big])
+    big = sorted(range(len(gap)), key=lambda i: gap[i])[-8:]
+    print("largest gaps (us) and the pass they follow:", ["%.0f after pass %d" % (gap[i], i) for i in sorted(big)])
     # everything the device ran across three consecutive passes in the middle of the repetition
     mid = last[len(last) // 2]
     t_ref = rows[mid][0]

@@ -248,6 +248,8 @@ static void decode_launch_quant(whisper_context & ctx, whisper_state & st, int n
 // taking the slot gives it back itself).  While a window owns the slot, other states' single-token steps on that device wait; steps
 // that do not need the slot (several tokens, masks, beams: the launch sequence) run concurrently on their own streams.
 static std::mutex & mega_slot(int device) { static std::mutex m[64]; return m[(unsigned) device & 63u]; }
+// (tests) every cross soft-max total of the several-rows kernel through its in-order path
+static int rows_force_inorder() { static const int v = getenv("WHISPER_AMD_ROWS_FORCE_INORDER") != nullptr ? 1 : 0; return v; }
 
 // a one-launch form gave up at a hand-off: pause it (the launch sequence serves meanwhile), try again later, give up for good after 8 time-outs
 static void one_launch_timeout(int & pause, int & timeouts, bool & enabled, const char * what, unsigned status) {
@@ -323,7 +325,7 @@ static int rows_step(whisper_context & ctx, whisper_state & bst, int B, const wa
         if (rows[i].n_kv < 1 || rows[i].n_kv > WA_ROWS_MAXKV || rows[i].kv_head < 0 || rows[i].kv_head >= rows[i].n_kv) return 0;
     const int n_wg = std::min(m.n_cu, 256);
     wa_rows_args a;
-    memset(&a, 0, sizeof(a));
+    memset(&a, 0, sizeof(a)); a.force_inorder = rows_force_inorder();
     const int quant = m.wtype != 1 ? 1 : 0;
     if (wa_rows_lds_bytes(hp.n_text_state, B, n_wg, quant, &a.slot_bytes) == 0) return 0;
     if (!wa_rows_prepare(ctx, bst)) return 0;
@@ -425,7 +427,7 @@ static bool spec_launch_rows(whisper_context & ctx, whisper_state & st, int k, i
     const int n_wg = std::min(m.n_cu, 256), quant = m.wtype != 1 ? 1 : 0, n_kv = pos + 1;
     if (!st.rows_enabled || st.rows_pause > 0 || n_kv > WA_ROWS_MAXKV || T < 1 || (T >> 5) > 47 || T > st.cross_tpad) return false;
     wa_rows_args a;
-    memset(&a, 0, sizeof(a));
+    memset(&a, 0, sizeof(a)); a.force_inorder = rows_force_inorder();
     if (wa_rows_lds_bytes(hp.n_text_state, 1, n_wg, quant, &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, st)) return false;
     const int b = k & 1;
     a.layers = (const wa_mega_layer *) m.d_mega_layers;
@@ -661,7 +663,7 @@ static bool batcher_launch_async(wa_batcher & b, wa_bslot ** run, int B, int T, 
     if (!bs.rows_enabled || bs.rows_pause > 0 || !batcher_async_prepare(b) || T < 1 || (T >> 5) > 47 || T > bs.cross_tpad) return false;
     const int n_wg = std::min(m.n_cu, 256), quant = m.wtype != 1 ? 1 : 0;
     wa_rows_args a;
-    memset(&a, 0, sizeof(a));
+    memset(&a, 0, sizeof(a)); a.force_inorder = rows_force_inorder();
     if (wa_rows_lds_bytes(hp.n_text_state, B, n_wg, quant, &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, bs)) return false;
     for (int i = 0; i < B; ++i) { const wa_breq & r = *batcher_next(*run[i]); if (r.n_kv < 1 || r.n_kv > WA_ROWS_MAXKV || r.kv_head < 0 || r.kv_head >= r.n_kv) return false; }
     const int par = (int) (b.n_launched & 1);
@@ -1172,7 +1174,7 @@ extern "C" int whisper_amd_rows_enabled(struct whisper_state * st) { return st &
 static bool rows_probe_args(whisper_context & ctx, whisper_state & own, whisper_state ** sts, int B, const int * tokens, int n_past, wa_rows_args & a) {
     const auto & m = ctx.model; const auto & hp = m.hp;
     const int T = own.enc_n_ctx > 0 ? own.enc_n_ctx : hp.n_audio_ctx;
-    memset(&a, 0, sizeof(a));
+    memset(&a, 0, sizeof(a)); a.force_inorder = rows_force_inorder();
     if (B < 1 || B > WA_ROWS_MAX || !own.rows_enabled || n_past < 0 || n_past + 1 > (int) own.kv_self.size || n_past + 1 > WA_ROWS_MAXKV || (T >> 5) > 47) return false;
     const int quant = m.wtype != 1 ? 1 : 0;
     if (wa_rows_lds_bytes(hp.n_text_state, B, std::min(m.n_cu, 256), quant, &a.slot_bytes) == 0 || !wa_rows_prepare(ctx, own)) return false;

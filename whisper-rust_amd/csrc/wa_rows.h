@@ -54,6 +54,7 @@ struct wa_rows_args {
     int * tok_out;                                      // [B] the token every row decoded (given, or picked from its records), null: not wanted
     float kq_scale; unsigned seq;
     int B, slot_bytes;
+    int force_inorder;                                  // tests (WHISPER_AMD_ROWS_FORCE_INORDER): every cross soft-max total takes the in-order path of mb_unit_cross
     int token_beg, token_eot;                           // (records) first timestamp token, end-of-text token
     int n_out, out_row[WA_ROWS_MAX];                    // token rows whose logits are wanted (the reference flags batch.logits rows): logits row m = token row out_row[m]
     wa_rows_row rows[WA_ROWS_MAX];

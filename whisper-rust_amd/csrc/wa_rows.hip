@@ -700,6 +700,7 @@ __device__ __forceinline__ void mb_unit_self(mb_kargs A, mb_ctl & c, unsigned ch
 #define MB_CGR_MAX 0
 #define MB_CGR_SUM 8
 #define MB_CGR_PART 64               // chain sums of the parts 1 .. P - 1: [P - 1][NCH][64]; behind them their leftover probabilities [P - 1][NCH]
+#define MB_CGR_INORD 1664            // (quarters, rare) the parts' group sums for the in-order total: [4][64] = 48 group sums | 8 tail cells | 8 unused
 
 template <int P> struct mb_cross_regs { u32x4 ka[12 / P], kb[12 / P]; unsigned short vv[4 / P][MB_CSTEPS]; };
 // own keys and own chain elements: unconditional, clamped loads - all in flight together
@@ -826,8 +827,42 @@ __device__ __forceinline__ void mb_unit_cross(mb_kargs A, mb_ctl & c, unsigned c
         }
         const double delta = (double) (ng + 8 + 16) * 0x1p-53 * tot * 1.000001;      // (as in the self-attention unit: reference (ng + 7) u S + this tree's 16 u S)
         const float ilo = (float) (1.0 / (tot + delta)), ihi = (float) (1.0 / (tot - delta));
-        if (ilo != ihi && lane == 0) ((GAS unsigned *) A->row_status)[b] = (unsigned) WA_MEGA_REDO;      // (this row only: the pass goes on)
-        if (lane == 0) bc[1] = ilo;
+        float inv_ = ilo;
+        if (ilo != ihi || A->force_inorder) {       // the order could matter (~3e-5 per soft-max; the same decision in every part: they hold the same total)
+            if constexpr (P == 4) {
+                // The reference's order (vec.cpp:278-305: the group sums one after the other in F64, then the n % 8 tail cells), inside the launch: every quarter
+                // publishes its 47-48 group sums (the tree of ops.cpp over its exponentials, as above) and the tail cells it owns, gathers all four quarters'
+                // and lets one lane add them in index order - group g = 4 s + w is step s of quarter w.  (Until late in round 3 the row was marked for the launch
+                // sequence instead: a 1-4 ms stall of a whole lock-step group, a few times per job.)
+                float * io = part;                  // [4][64] scratch (the chain sums come later)
+                gu64 * XI = X + MB_CGR_INORD;
+                {
+                    const int s_ = lane;            // slots 0..47: step s of this quarter; 48..55: the cells of the partial group, if this quarter owns it; the rest: 0
+                    float pv = 0.0f;
+                    if (s_ < MB_CSTEPS) {
+                        const float * e8 = sc + 8 * s_;
+                        if (4 * s_ + w < ng) pv = ((e8[0] + e8[4]) + (e8[2] + e8[6])) + ((e8[1] + e8[5]) + (e8[3] + e8[7]));
+                    } else if (s_ < MB_CSTEPS + 8) {
+                        const int j = s_ - MB_CSTEPS, st = ng >> 2;         // group ng = step ng / 4 of quarter ng % 4: the cells n8 + j
+                        if ((ng & 3) == w && st < MB_CSTEPS && n8 + j < T) pv = sc[8 * st + j];
+                    }
+                    gr_store(XI + 64 * w + s_, seq, __float_as_uint(pv));
+                }
+                unsigned vi[4];
+                mb_sweep<4>(XI, [&](int k) { return 64 * k + lane; }, c, lane, vi, 2250u + l);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) io[64 * k + lane] = __uint_as_float(vi[k]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (this wave's own LDS writes, read back below)
+                double so = 0.0;
+                for (int s_ = 0; s_ < MB_CSTEPS; ++s_)
+                    for (int q = 0; q < 4; ++q) if (4 * s_ + q < ng) so += (double) io[64 * q + s_];
+                for (int j = 0; n8 + j < T; ++j) so += (double) io[64 * (ng & 3) + MB_CSTEPS + j];
+                inv_ = (float) (1.0 / so);
+            } else {
+                if (lane == 0) ((GAS unsigned *) A->row_status)[b] = (unsigned) WA_MEGA_REDO;      // (halves: not instantiated - this row goes to the launch sequence, the pass goes on)
+            }
+        }
+        if (lane == 0) bc[1] = inv_;
     }
     mb_barrier();
     MB_TC(6);
