@@ -992,7 +992,12 @@ __device__ __forceinline__ void mb_te_first(mb_kargs A, bool quant, unsigned (&b
         const GAS unsigned * wl = (const GAS unsigned *) A->te + ((size_t) rc * 8 + u) * ns;
         const GAS unsigned * dl = (const GAS unsigned *) A->te_d + (size_t) rc * ns;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) { const int bc = k < ns ? k : ns - 1; buf[k] = wl[bc]; buf[24 + k] = dl[bc]; }
+        for (int k4 = 0; k4 < 6; ++k4) {         // 16 bytes = four blocks per load (a row's quads of a lane and its scales are contiguous; d / 32 is a multiple of 4):
+            const int bc = 4 * k4 < ns ? 4 * k4 : ns - 4;         // as single dwords a piece was 48 load instructions of 64 scattered 4-byte accesses each
+            const u32x4 q = *(const GAS u32x4 *) (wl + bc), sd = *(const GAS u32x4 *) (dl + bc);
+            buf[4 * k4] = q.x; buf[4 * k4 + 1] = q.y; buf[4 * k4 + 2] = q.z; buf[4 * k4 + 3] = q.w;
+            buf[24 + 4 * k4] = sd.x; buf[24 + 4 * k4 + 1] = sd.y; buf[24 + 4 * k4 + 2] = sd.z; buf[24 + 4 * k4 + 3] = sd.w;
+        }
     }
 }
 
@@ -1083,7 +1088,12 @@ __device__ __forceinline__ void mb_logits_q(mb_kargs A, const unsigned char * xo
         const GAS unsigned * wl = (const GAS unsigned *) A->te + ((size_t) rc * 8 + u) * nb;
         const GAS unsigned * dl = (const GAS unsigned *) A->te_d + (size_t) rc * nb;
 #pragma unroll
-        for (int k = 0; k < 24; ++k) { const int bb = bt * 24 + k, bc = bb < nb ? bb : nb - 1; buf[k] = wl[bc]; buf[24 + k] = dl[bc]; }
+        for (int k4 = 0; k4 < 6; ++k4) {         // (16-byte loads: mb_te_first)
+            const int bb = bt * 24 + 4 * k4, bc = bb < nb ? bb : nb - 4;
+            const u32x4 q = *(const GAS u32x4 *) (wl + bc), sd = *(const GAS u32x4 *) (dl + bc);
+            buf[4 * k4] = q.x; buf[4 * k4 + 1] = q.y; buf[4 * k4 + 2] = q.z; buf[4 * k4 + 3] = q.w;
+            buf[24 + 4 * k4] = sd.x; buf[24 + 4 * k4 + 1] = sd.y; buf[24 + 4 * k4 + 2] = sd.z; buf[24 + 4 * k4 + 3] = sd.w;
+        }
     };
     float acc[BT];
     const unsigned char * xq[BT], * xd[BT];
